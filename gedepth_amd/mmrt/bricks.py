@@ -1,0 +1,283 @@
+"""Module bricks the reference takes from mmcv 1.3.13 (not vendored there).
+
+Each brick restates the mmcv semantics listed in SURVEY.md Appendix A so that
+state-dict key names, default hyper-parameters and initialisation of the
+reference's modules are reproduced without mmcv:
+``BaseModule/ModuleList/Sequential`` (depth/models/backbones/depthformer_swin.py:12),
+``ConvModule`` (necks/hahi.py:3, decode_heads/densedepth_head.py:4),
+``build_norm_layer`` (depthformer_swin.py:8,437,1040), ``FFN``/``build_dropout``
+(depthformer_swin.py:9,283,451-459), weight-init helpers.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from .registry import Registry, build_from_cfg
+
+MODELS = Registry('model')
+ATTENTION = Registry('attention')
+POSITIONAL_ENCODING = Registry('position encoding')
+DROPOUT_LAYERS = Registry('drop out layers')
+
+
+# ----------------------------------------------------------------------------------- init
+def constant_init(module, val, bias=0):
+    if hasattr(module, 'weight') and module.weight is not None:
+        nn.init.constant_(module.weight, val)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    assert distribution in ['uniform', 'normal']
+    if hasattr(module, 'weight') and module.weight is not None:
+        if distribution == 'uniform':
+            nn.init.xavier_uniform_(module.weight, gain=gain)
+        else:
+            nn.init.xavier_normal_(module.weight, gain=gain)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+    assert distribution in ['uniform', 'normal']
+    if hasattr(module, 'weight') and module.weight is not None:
+        if distribution == 'uniform':
+            nn.init.kaiming_uniform_(module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+        else:
+            nn.init.kaiming_normal_(module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def trunc_normal_init(module, mean=0., std=1., a=-2., b=2., bias=0.):
+    """Accepts a module (weight/bias) or a bare parameter, as the reference
+    calls it both ways (depthformer_swin.py:182,1049-1053)."""
+    if isinstance(module, torch.Tensor):
+        nn.init.trunc_normal_(module, mean, std, a, b)
+        return
+    if hasattr(module, 'weight') and module.weight is not None:
+        nn.init.trunc_normal_(module.weight, mean, std, a, b)
+    if hasattr(module, 'bias') and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+# ----------------------------------------------------------------------------------- base
+class BaseModule(nn.Module):
+    """nn.Module + ``init_cfg`` + one-shot recursive ``init_weights``."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self._is_init = False
+        self.init_cfg = init_cfg
+
+    @property
+    def is_init(self):
+        return self._is_init
+
+    def init_weights(self):
+        if self._is_init:
+            warnings.warn(f'init_weights of {self.__class__.__name__} has been called more than once.')
+            return
+        for m in self.children():
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+        self._is_init = True
+
+
+class Sequential(BaseModule, nn.Sequential):
+
+    def __init__(self, *args, init_cfg=None):
+        BaseModule.__init__(self, init_cfg)
+        nn.Sequential.__init__(self, *args)
+
+
+class ModuleList(BaseModule, nn.ModuleList):
+
+    def __init__(self, modules=None, init_cfg=None):
+        BaseModule.__init__(self, init_cfg)
+        nn.ModuleList.__init__(self, modules)
+
+
+# ----------------------------------------------------------------------------------- layers
+_NORM = {
+    'BN': ('bn', nn.BatchNorm2d), 'BN1d': ('bn', nn.BatchNorm1d), 'BN2d': ('bn', nn.BatchNorm2d),
+    'SyncBN': ('bn', nn.SyncBatchNorm), 'GN': ('gn', nn.GroupNorm), 'LN': ('ln', nn.LayerNorm),
+    'IN': ('in', nn.InstanceNorm2d),
+}
+_ACT = {
+    'ReLU': nn.ReLU, 'LeakyReLU': nn.LeakyReLU, 'PReLU': nn.PReLU, 'ReLU6': nn.ReLU6, 'ELU': nn.ELU,
+    'Sigmoid': nn.Sigmoid, 'Tanh': nn.Tanh, 'GELU': nn.GELU,
+}
+_CONV = {'Conv1d': nn.Conv1d, 'Conv2d': nn.Conv2d, 'Conv3d': nn.Conv3d, 'Conv': nn.Conv2d}
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    if not isinstance(cfg, dict) or 'type' not in cfg:
+        raise KeyError('the cfg dict must contain the key "type"')
+    cfg_ = dict(cfg)
+    layer_type = cfg_.pop('type')
+    if layer_type not in _NORM:
+        raise KeyError(f'Unrecognized norm type {layer_type}')
+    abbr, norm_layer = _NORM[layer_type]
+    name = abbr + str(postfix)
+    requires_grad = cfg_.pop('requires_grad', True)
+    cfg_.setdefault('eps', 1e-5)
+    if layer_type == 'GN':
+        assert 'num_groups' in cfg_
+        layer = norm_layer(num_channels=num_features, **cfg_)
+    else:
+        layer = norm_layer(num_features, **cfg_)
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return name, layer
+
+
+def build_activation_layer(cfg):
+    cfg_ = dict(cfg)
+    t = cfg_.pop('type')
+    if t not in _ACT:
+        raise KeyError(f'Unrecognized activation type {t}')
+    return _ACT[t](**cfg_)
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    cfg_ = dict(type='Conv2d') if cfg is None else dict(cfg)
+    t = cfg_.pop('type')
+    if t not in _CONV:
+        raise KeyError(f'Unrecognized conv type {t}')
+    return _CONV[t](*args, **kwargs, **cfg_)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> act block; sub-module names ``conv``, ``bn``/``ln``…, ``activate``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True,
+                 order=('conv', 'norm', 'act')):
+        super().__init__()
+        assert order == ('conv', 'norm', 'act'), 'only the conv-norm-act order is on the GEDepth path'
+        self.conv_cfg, self.norm_cfg, self.act_cfg = conv_cfg, norm_cfg, act_cfg
+        self.inplace = inplace
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.with_bias = bias
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, groups=groups, bias=bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        else:
+            self.norm_name = None
+        if self.with_activation:
+            act_cfg_ = dict(act_cfg)
+            if act_cfg_['type'] not in ['Tanh', 'PReLU', 'Sigmoid', 'GELU']:
+                act_cfg_.setdefault('inplace', inplace)
+            self.activate = build_activation_layer(act_cfg_)
+        self.init_weights()
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.norm_name else None
+
+    def init_weights(self):
+        if self.with_activation and self.act_cfg['type'] == 'LeakyReLU':
+            nonlinearity, a = 'leaky_relu', self.act_cfg.get('negative_slope', 0.01)
+        else:
+            nonlinearity, a = 'relu', 0
+        kaiming_init(self.conv, a=a, nonlinearity=nonlinearity)
+        if self.with_norm:
+            constant_init(self.norm, 1, bias=0)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.norm(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+def drop_path(x, drop_prob=0., training=False):
+    if drop_prob == 0. or not training:
+        return x
+    keep_prob = 1 - drop_prob
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    random_tensor = keep_prob + torch.rand(shape, dtype=x.dtype, device=x.device)
+    return x.div(keep_prob) * random_tensor.floor()
+
+
+@DROPOUT_LAYERS.register_module()
+class DropPath(nn.Module):
+    """Per-sample stochastic depth."""
+
+    def __init__(self, drop_prob=0.1):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)
+
+
+@DROPOUT_LAYERS.register_module()
+class Dropout(nn.Dropout):
+
+    def __init__(self, drop_prob=0.5, inplace=False):
+        super().__init__(p=drop_prob, inplace=inplace)
+
+
+def build_dropout(cfg, default_args=None):
+    return build_from_cfg(cfg, DROPOUT_LAYERS, default_args)
+
+
+def build_positional_encoding(cfg, default_args=None):
+    return build_from_cfg(cfg, POSITIONAL_ENCODING, default_args)
+
+
+class FFN(BaseModule):
+    """Linear(C,4C)-act-drop-Linear(4C,C)-drop with identity add; keys
+    ``layers.0.0.*`` / ``layers.1.*`` (consistent with models/utils/ckpt_convert.py:29-32)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        assert num_fcs >= 2
+        self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
+        self.act_cfg = act_cfg
+        self.activate = build_activation_layer(act_cfg)
+        layers, in_channels = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(Sequential(nn.Linear(in_channels, feedforward_channels), self.activate,
+                                     nn.Dropout(ffn_drop)))
+            in_channels = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = Sequential(*layers)
+        self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+def msda_offset_bias(num_heads, num_levels, num_points):
+    """Initial ``sampling_offsets.bias`` of mmcv's MultiScaleDeformableAttention
+    (unit directions / max-abs component, scaled by point index + 1)."""
+    thetas = torch.arange(num_heads, dtype=torch.float32) * (2.0 * math.pi / num_heads)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(num_heads, 1, 1, 2).repeat(
+        1, num_levels, num_points, 1)
+    for i in range(num_points):
+        grid[:, :, i, :] *= i + 1
+    return grid.view(-1)

@@ -1,0 +1,189 @@
+"""Pin the CPU oracle (oracle/gedepth_oracle.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py) and against the closed-form known answers of SURVEY.md Appendix E."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gedepth_oracle as O
+from oracle.fill import fill_state_dict
+
+RTOL, ATOL = 1e-4, 1e-5      # fp32 tolerance stated by BASELINE.json north_star (1e-4 rel)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def weights(g, salt, key='spec', prefix=''):
+    spec = json.loads(str(g[key]))
+    P = fill_state_dict([(n, s) for n, s in spec], salt)
+    return {prefix + k: v for k, v in P.items()}
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f'max abs err {err.max():.3e}, max rel {(err / (b.abs() + 1e-12)).max():.3e}'
+
+
+def test_relative_position_index(golden):
+    g = golden('window_msa')
+    idx = O.relative_position_index()
+    assert torch.equal(idx, T(g['rel_index']))
+    i = torch.arange(49) // 7
+    j = torch.arange(49) % 7
+    analytic = (i[:, None] - i[None, :] + 6) * 13 + (j[:, None] - j[None, :] + 6)
+    assert torch.equal(idx, analytic)
+
+
+def test_window_msa(golden):
+    g = golden('window_msa')
+    P = weights(g, 'window_msa', prefix='w.')
+    close(O.window_msa(T(g['x']), None, P, 'w', 3), g['out_nomask'])
+    close(O.window_msa(T(g['x']), T(g['mask']), P, 'w', 3), g['out_mask'])
+
+
+@pytest.mark.parametrize('tag,hw', [('a', (11, 35)), ('b', (10, 9))])
+@pytest.mark.parametrize('shift', [0, 3])
+def test_shift_window_msa(golden, tag, hw, shift):
+    g = golden('shift_window_msa')
+    P = weights(g, 'shift_window_msa', prefix='a.')
+    close(O.shift_window_msa(T(g[f'x_{tag}{shift}']), hw, P, 'a', 3, shift), g[f'out_{tag}{shift}'])
+
+
+def test_analytic_shift_mask():
+    """region id r(h)=0 if h<Hp-7, 1 if h<Hp-3 else 2; id=3 r(h)+r(w)."""
+    for Hp, Wp in [(14, 35), (21, 28), (7, 7)]:
+        ref = O.shift_mask(Hp, Wp)
+        r = lambda t, n: (t >= n - 7).long() + (t >= n - 3).long()
+        hh, ww = torch.meshgrid(torch.arange(Hp), torch.arange(Wp), indexing='ij')
+        ids = (3 * r(hh, Hp) + r(ww, Wp)).float().view(1, Hp, Wp, 1)
+        mw = O.window_partition(ids).view(-1, 49)
+        m = (mw[:, None, :] != mw[:, :, None]).float() * -100.0
+        assert torch.equal(m, ref)
+
+
+def test_swin_block_merging_embed(golden):
+    g = golden('swin_block')
+    close(O.swin_block(T(g['x']), (11, 13), weights(g, 'swin_block', prefix='b.'), 'b', 3, 3), g['out'])
+    g = golden('patch_merging')
+    out, hw = O.patch_merging(T(g['x']), (5, 7), weights(g, 'patch_merging', prefix='d.'), 'd')
+    close(out, g['out'])
+    assert tuple(hw) == tuple(g['hw'])
+
+
+def test_msda(golden):
+    g = golden('msda_core')
+    shapes = [tuple(int(v) for v in s) for s in g['shapes']]
+    close(O.msda_core(T(g['value']), shapes, T(g['loc']), T(g['aw'])), g['out'])
+    g = golden('msda_module')
+    P = weights(g, 'msda_module', prefix='m.')
+    close(O.msda_module(T(g['q']), T(g['v']), T(g['qp']), T(g['ref']), shapes, P, 'm'), g['out'])
+
+
+def test_msda_core_vs_transformers(golden):
+    """Independent pin of the un-vendored mmcv sampling core."""
+    tr = pytest.importorskip('transformers.models.deformable_detr.modeling_deformable_detr')
+    cls = getattr(tr, 'MultiScaleDeformableAttention', None)
+    if cls is None:
+        pytest.skip('no reference implementation in this transformers build')
+    g = golden('msda_core')
+    shapes = [tuple(int(v) for v in s) for s in g['shapes']]
+    try:
+        out = cls()(T(g['value']), torch.as_tensor(shapes), shapes, None, T(g['loc']), T(g['aw']), 64)
+    except TypeError:
+        pytest.skip('transformers signature differs')
+    assert torch.equal(out, T(g['out']))
+
+
+def test_sine_pos(golden):
+    close(O.sine_positional_encoding(1, 5, 7), golden('sine_pos')['out'])
+
+
+def test_hahi(golden):
+    g = golden('hahi')
+    P = weights(g, 'hahi', prefix='neck.')
+    feats = [T(g[f'in{i}']) for i in range(5)]
+    for mode, train in (('eval', False), ('train', True)):
+        outs = O.hahi_neck(feats, P, train_bn=train)
+        for i, o in enumerate(outs):
+            close(o, g[f'{mode}_out{i}'], rtol=2e-4, atol=2e-5)
+
+
+def test_pe_necks(golden):
+    g = golden('pe_necks')
+    feats = [T(g[f'in{i}']) for i in range(5)]
+    close(O.pe_mask_neck(feats, weights(g, 'pe_mask_neck', 'spec_mask', 'pe_mask_neck.')), g['y'])
+    close(O.dynamic_pe_neck(feats, weights(g, 'dynamic_pe_neck', 'spec_dyn', 'dynamic_pe_neck.')), g['logits'])
+
+
+def test_dynamic_pe(golden):
+    g = golden('dynamic_pe')
+    img = T(g['img'])
+    pe_mask, logits, m = O.dynamic_pe(T(g['logits_lr']), T(g['y']), img[:, 4])
+    close(logits, g['logits_hr'])
+    close(pe_mask, g['pe_mask'], atol=1e-4)
+    assert set(np.unique(m.numpy())) <= {0.0, 1.0}
+    pe_mask_h, _, _ = O.dynamic_pe(T(g['logits_lr']), T(g['y']), img[:, 4], height=T(g['heights']))
+    close(pe_mask_h, g['pe_mask_h'], atol=1e-4)
+    close(O.vanilla_pe(T(g['y']), img[:, 3]), g['vanilla'])
+
+
+def test_known_answers(golden):
+    g = golden('known_answers')
+    close(O.sigloss(T(g['sig_pred']), T(g['sig_gt'])), g['sig'])
+    assert abs(float(g['sig']) - 0.28163391) < 1e-6
+    close(O.ce_loss(T(g['ce_logits']), T(g['ce_target'])), g['ce'])
+    mt = O.metrics_calculate(np.array([1.5, 3, 8, 12, 25, 60.]), np.array([1., 4, 8, 10, 20, 79.]))
+    np.testing.assert_allclose(mt, g['metrics'], rtol=1e-12)
+    np.testing.assert_allclose(mt[3], 0.225, rtol=1e-9)
+    np.testing.assert_allclose(mt[4], 8.0751677, rtol=1e-7)
+
+
+def test_ground_plane_known_answers():
+    """SURVEY Appendix E (values measured on the reference formula, tools/preprocess_data_kitti.py:47-53)."""
+    P2 = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01],
+                   [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01],
+                   [0.0, 0.0, 1.0, 2.745884e-03]])
+    Tr = np.array([[0., -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]])
+    pe, _, _ = O.ground_plane(P2, np.eye(3), Tr, 375, 1242)
+    np.testing.assert_allclose(pe[374, 621], 5.630516794, rtol=1e-8)
+    np.testing.assert_allclose(pe[200, 100], 41.720913986, rtol=1e-8)
+    np.testing.assert_allclose(pe[100, 621], -15.545555921, rtol=1e-8)
+    k = O.slope_class(np.array([[10., 0], [30, 5]]), np.array([[11, 20], [25, 5.2]], dtype=np.float32))
+    assert k.tolist() == [[1, 255], [-1, 1]]
+
+
+@pytest.mark.parametrize('tag,arch,adaptive', [('e2e_T_V', O.SWIN_T, False), ('e2e_T_A', O.SWIN_T, True),
+                                               ('e2e_L_A', O.SWIN_L, True)])
+def test_e2e(golden, tag, arch, adaptive):
+    g = golden(tag)
+    P = weights(g, 'e2e')
+    for v in P.values():
+        v.requires_grad_(v.is_floating_point())
+    for k in P:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            P[k].requires_grad_(False)
+    cfg = dict(arch, adaptive=adaptive)
+    img, gt, kgt = T(g['img']), T(g['depth_gt']), T(g['pe_k_gt'])
+    with torch.no_grad():
+        close(O.encode_decode(img, P, cfg), g['depth_eval'], rtol=3e-4, atol=1e-4)
+    losses, _ = O.forward_train(img, gt, kgt, P, cfg, train_bn=True)
+    loss, log_vars = O.parse_losses(losses)
+    names = json.loads(str(g['loss_names']))
+    for n, v in zip(names, g['loss_values']):
+        assert abs(log_vars[n] - v) <= 2e-4 * abs(v) + 1e-5, (n, log_vars[n], v)
+    loss.backward()
+    for k in g.files:
+        if k.startswith('grad::'):
+            gr = P[k[6:]].grad.flatten()
+            gr = gr[::max(1, gr.numel() // 50000)]
+            ref = T(g[k])
+            scale = ref.abs().max().item() + 1e-12
+            assert (gr - ref).abs().max().item() <= 2e-3 * scale, (k, (gr - ref).abs().max().item(), scale)
+    total = torch.sqrt(sum((v.grad ** 2).sum() for v in P.values() if v.grad is not None))
+    assert abs(total.item() - float(g['grad_norm_total'])) <= 1e-3 * float(g['grad_norm_total'])
