@@ -1,0 +1,60 @@
+// Shared device helpers for the gfx950 kernels of libgedepth_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gedepth_hip.h"
+
+#define GE_WAVE 64
+
+#define GE_LAUNCH_CHECK()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, like torch
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Io;
+template <> struct Io<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rt(float v) { return v; }   // round-trip through storage type
+};
+template <> struct Io<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ float rt(float v) { return bf2f(f2bf(v)); }
+};
+
+// F.interpolate(mode='bilinear') source-index rule (scale from sizes, not from scale_factor).
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ float ge_scale(int in, int out, bool align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+__device__ __forceinline__ Lerp ge_lerp(int dst, int in, float scale, bool align) {
+  float src = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  Lerp r;
+  r.i0 = (int)src;
+  if (r.i0 > in - 1) r.i0 = in - 1;
+  r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+  r.w1 = src - (float)r.i0;
+  r.w0 = 1.f - r.w1;
+  return r;
+}
+
+static inline hipStream_t ge_stream(void* s) { return (hipStream_t)s; }
+static inline unsigned ge_blocks(long n, int per_block, long cap = 1 << 20) {
+  long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}

@@ -1,0 +1,187 @@
+"""HAHI neck (hierarchical aggregation / heterogeneous interaction) on the HIP deformable-attention op.
+
+Interface mirror of depth/models/necks/hahi.py:82-356 (constructor kwargs, state-dict keys
+``lateral_convs / trans_proj / trans_fusion / conv_proj / conv_fusion / reference_points / level_embed /
+multi_att / self_attn``) and of the mmcv 1.3.13 ``MultiScaleDeformableAttention`` module it instantiates
+(keys ``sampling_offsets / attention_weights / value_proj / output_proj``).
+
+MI355X-first differences: sine position embeddings, self-attention reference points and the
+cross-attention reference points are input-independent for a fixed feature shape (all masks are all-false,
+``valid_ratios == 1``; the cross-attention points are ``sigmoid(Linear(pos_embed))``, hahi.py:299-300), so
+the embeddings / pixel-centre points are cached per shape, and the sampling core is one gather kernel
+(gedepth_amd/csrc/msda.hip) instead of mmcv's CUDA extension.
+"""
+import torch
+import torch.nn as nn
+
+from ....kernels import ms_deform_attn
+from ....mmrt import bricks
+from ....mmrt.bricks import BaseModule, ConvModule, build_positional_encoding, xavier_init
+from ..builder import ATTENTION, NECKS
+
+
+@ATTENTION.register_module()
+class MultiScaleDeformableAttention(BaseModule):
+    """mmcv-compatible module; forward supports the 2-d reference-point form used by HAHI."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}')
+        if embed_dims // num_heads != 64:
+            raise NotImplementedError('the HIP sampling kernel is specialised for 64 channels per head')
+        self.norm_cfg, self.batch_first = norm_cfg, batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.im2col_step = im2col_step
+        self.embed_dims, self.num_levels, self.num_heads, self.num_points = embed_dims, num_levels, num_heads, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        bricks.constant_init(self.sampling_offsets, 0.)
+        self.sampling_offsets.bias.data = bricks.msda_offset_bias(self.num_heads, self.num_levels, self.num_points)
+        bricks.constant_init(self.attention_weights, val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+        self._is_init = True
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query                      # BEFORE the positional embedding is added
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        num_value = value.shape[1]
+        if torch.is_tensor(spatial_shapes):
+            spatial_shapes = [(int(h), int(w)) for h, w in spatial_shapes.tolist()]
+        assert sum(h * w for h, w in spatial_shapes) == num_value
+        if reference_points.shape[-1] != 2:
+            raise ValueError('only 2-d reference points are used on the GEDepth path')
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        nH, L, P = self.num_heads, self.num_levels, self.num_points
+        offsets = self.sampling_offsets(query).float().view(bs, num_query, nH, L, P, 2)
+        weights = self.attention_weights(query).float().view(bs, num_query, nH, L * P).softmax(-1)
+        weights = weights.view(bs, num_query, nH, L, P)
+        # sampling locations stay fp32 (pixel coordinates up to ~1000 need > 8 mantissa bits)
+        normalizer = torch.tensor([[w, h] for h, w in spatial_shapes], dtype=torch.float32, device=query.device)
+        loc = reference_points.float()[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        out = ms_deform_attn(value, spatial_shapes, loc, weights)
+        out = self.output_proj(out)
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return self.dropout(out) + identity
+
+
+@NECKS.register_module()
+class HAHIHeteroNeck(BaseModule):
+
+    def __init__(self, in_channels, out_channels, embedding_dim, scales=[1, 1, 1, 1],
+                 norm_cfg=dict(type='BN', requires_grad=True), act_cfg=dict(type='ReLU', inplace=True),
+                 cross_att=True, self_att=True, constrain=False, positional_encoding=None, num_points=8):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        assert all(s == 1 for s in scales), 'GEDepth configs use scale 1 at every level'
+        self.cross_att, self.self_att, self.constrain = cross_att, self_att, constrain
+        self.in_channels, self.out_channels, self.scales = in_channels, out_channels, scales
+        self.num_outs = len(scales)
+        self.embedding_dim = E = embedding_dim
+        cm = dict(norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.lateral_convs = nn.ModuleList(ConvModule(i, o, kernel_size=1, **cm) for i, o in zip(in_channels, out_channels))
+        self.trans_proj = nn.ModuleList(ConvModule(o, E, kernel_size=1, **cm) for o in out_channels[1:])
+        self.trans_fusion = nn.ModuleList(ConvModule(o + E, o, kernel_size=3, padding=1, stride=1, **cm)
+                                          for o in out_channels[1:])
+        self.conv_proj = nn.Sequential(ConvModule(in_channels[0], E, kernel_size=1, **cm))
+        self.conv_fusion = nn.Sequential(ConvModule(in_channels[0] + E, out_channels[0], kernel_size=3, padding=1,
+                                                    stride=1, **cm))
+        self.trans_positional_encoding = build_positional_encoding(positional_encoding)
+        self.conv_positional_encoding = build_positional_encoding(positional_encoding)
+        self.reference_points = nn.Linear(E, 2)
+        self.level_embed = nn.Parameter(torch.Tensor(4, E))
+        att = dict(embed_dims=E, num_levels=4, num_heads=8, num_points=num_points, batch_first=True)
+        self.multi_att = MultiScaleDeformableAttention(**att)
+        self.self_attn = MultiScaleDeformableAttention(**att)
+        self._ref_cache = {}
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        nn.init.xavier_uniform_(self.reference_points.weight.data, gain=1.0)
+        nn.init.constant_(self.reference_points.bias.data, 0.)
+        nn.init.normal_(self.level_embed)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m, distribution='uniform')
+            if isinstance(m, MultiScaleDeformableAttention):
+                m.init_weights()
+        self._is_init = True
+
+    def _pixel_centres(self, shapes, device):
+        """Self-attention reference points: normalised pixel centres per level (hahi.py:220-233, ratios == 1)."""
+        key = (tuple(shapes), str(device))
+        if key not in self._ref_cache:
+            pts = []
+            for h, w in shapes:
+                ry = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32, device=device) / h
+                rx = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32, device=device) / w
+                gy, gx = torch.meshgrid(ry, rx, indexing='ij')
+                pts.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+            ref = torch.cat(pts, 0)[None, :, None, :].expand(1, -1, len(shapes), 2).contiguous()
+            self._ref_cache[key] = ref
+        return self._ref_cache[key]
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        feats = [conv(x) for conv, x in zip(self.lateral_convs, inputs)]
+        feat_conv, feats_trans = feats[0], feats[1:]
+        bs = feat_conv.shape[0]
+        dev = feat_conv.device
+        shapes, srcs, poss = [], [], []
+        for i, ft in enumerate(feats_trans):
+            h, w = ft.shape[2:]
+            shapes.append((h, w))
+            pos = self.trans_positional_encoding.grid(h, w, dev).flatten(2).transpose(1, 2)
+            poss.append(pos + self.level_embed[i].view(1, 1, -1))
+            srcs.append(self.trans_proj[i](ft).flatten(2).transpose(1, 2))
+        src_flatten = torch.cat(srcs, 1)
+        pos_flatten = torch.cat(poss, 1).expand(bs, -1, -1)
+        if self.self_att:
+            ref = self._pixel_centres(shapes, dev).expand(bs, -1, -1, -1)
+            src = self.self_attn(src_flatten, value=None, identity=None, query_pos=pos_flatten,
+                                 reference_points=ref, spatial_shapes=shapes)
+        else:
+            src = src_flatten
+
+        conv_skip = self.conv_proj(feat_conv)
+        _, c, h, w = conv_skip.shape
+        query = conv_skip.flatten(2).transpose(1, 2)
+        query_embed = self.conv_positional_encoding.grid(h, w, dev).flatten(2).transpose(1, 2)
+        if self.cross_att:
+            # content-independent reference points: one (1, Nq, 2) evaluation, broadcast over batch and levels
+            ref = self.reference_points(query_embed.float()).sigmoid()
+            ref = ref[:, :, None, :].expand(bs, -1, len(shapes), 2)
+            fusion = self.multi_att(query, value=src, identity=None, query_pos=query_embed.expand(bs, -1, -1),
+                                    reference_points=ref, spatial_shapes=shapes)
+        else:
+            fusion = query
+        fusion = fusion.permute(0, 2, 1).reshape(bs, c, h, w)
+        outs = [self.conv_fusion(torch.cat([fusion, feat_conv], dim=1))]
+        start = 0
+        for i, ft in enumerate(feats_trans):
+            h, w = ft.shape[2:]
+            feat = src[:, start:start + h * w].permute(0, 2, 1).reshape(bs, self.embedding_dim, h, w)
+            start += h * w
+            outs.append(self.trans_fusion[i](torch.cat([ft, feat], dim=1)))
+        return tuple(outs)

@@ -1,0 +1,387 @@
+"""torch.autograd bindings of the HIP kernels (one Function per C-ABI op pair).
+
+PyTorch is used for device memory, streams and autograd plumbing only; every forward and
+backward below is a call into libgedepth_hip.so through gedepth_amd.hip (no eager fallback).
+"""
+import ctypes
+
+import torch
+
+from . import hip
+
+_f32 = torch.float32
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Profiler:
+    """Per-kernel HIP-event timing on the launch stream (bench.py's roofline object).  Off by default."""
+
+    def __init__(self):
+        self.on, self.records = False, {}
+
+    def enable(self):
+        self.on, self.records = True, {}
+
+    def disable(self):
+        self.on = False
+
+    def run(self, name, nbytes, call):
+        if not self.on:
+            return call()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        r = call()
+        e.record()
+        rec = self.records.setdefault(name, dict(bytes=int(nbytes), events=[]))
+        rec['events'].append((s, e))
+        return r
+
+    def summary(self):
+        if not self.records:
+            return []
+        torch.cuda.synchronize()
+        out = []
+        for name, rec in self.records.items():
+            ms = [s.elapsed_time(e) for s, e in rec['events']]
+            out.append(dict(name=name, launches=len(ms), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
+                            bytes_per_launch=rec['bytes']))
+        return out
+
+
+PROFILER = _Profiler()
+
+
+def _es(t):
+    return t.element_size()
+
+
+def _tag(t):
+    return 'bf16' if t.dtype == torch.bfloat16 else 'f32'
+
+
+# ------------------------------------------------------------------------ window attention
+class _WindowAttention(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, bias_table, H, W, num_heads, shift, scale, variant):
+        qkv = _c(qkv)
+        B, L, C3 = qkv.shape
+        assert L == H * W and C3 == 3 * num_heads * 32, (qkv.shape, H, W, num_heads)
+        qkv_bias = _c(qkv_bias.detach().to(_f32))
+        bias_table = _c(bias_table.detach().to(_f32))
+        out = torch.empty(B, L, C3 // 3, device=qkv.device, dtype=qkv.dtype)
+        nbytes = 4 * B * L * (C3 // 3) * _es(qkv) + 169 * num_heads * 4
+        PROFILER.run(f'window_attn_fwd[{B}x{H}x{W} nH{num_heads} s{shift} {_tag(qkv)} v{variant}]', nbytes, lambda: hip.check(
+            hip.lib().ge_window_attn_fwd(
+                hip.ptr(qkv, name='qkv'), hip.ptr(qkv_bias, _f32), hip.ptr(bias_table, _f32), hip.ptr(out),
+                B, H, W, num_heads, shift, scale, hip.dtype_code(qkv), variant, hip.stream()), 'ge_window_attn_fwd'))
+        ctx.save_for_backward(qkv, qkv_bias, bias_table)
+        ctx.geom = (B, H, W, num_heads, shift, scale, variant)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, qkv_bias, bias_table = ctx.saved_tensors
+        B, H, W, nH, shift, scale, variant = ctx.geom
+        d_out = _c(d_out.to(qkv.dtype))
+        d_qkv = torch.empty_like(qkv)
+        d_qb = torch.empty_like(qkv_bias)
+        d_tab = torch.empty_like(bias_table)
+        lib = hip.lib()
+        ws = torch.empty(max(int(lib.ge_window_attn_bwd_workspace(B, H, W, nH)), 4) // 4, device=qkv.device, dtype=_f32)
+        nbytes = 7 * qkv.numel() // 3 * _es(qkv)
+        PROFILER.run(f'window_attn_bwd[{B}x{H}x{W} nH{nH} s{shift} {_tag(qkv)} v{variant}]', nbytes, lambda: hip.check(
+            lib.ge_window_attn_bwd(
+                hip.ptr(qkv), hip.ptr(qkv_bias), hip.ptr(bias_table), hip.ptr(d_out), hip.ptr(d_qkv), hip.ptr(d_qb),
+                hip.ptr(d_tab), hip.ptr(ws), B, H, W, nH, shift, scale, hip.dtype_code(qkv), variant, hip.stream()),
+            'ge_window_attn_bwd'))
+        return d_qkv, d_qb, d_tab, None, None, None, None, None, None
+
+
+def window_attention(qkv, qkv_bias, bias_table, H, W, num_heads, shift, scale, variant=0):
+    """qkv (B, H*W, 3C) -> (B, H*W, C); see ge_window_attn_fwd in include/gedepth_hip.h."""
+    return _WindowAttention.apply(qkv, qkv_bias, bias_table, int(H), int(W), int(num_heads), int(shift),
+                                  float(scale), int(variant))
+
+
+# ------------------------------------------------------------------------------------ MSDA
+def _levels(spatial_shapes):
+    flat = [int(v) for hw in spatial_shapes for v in hw]
+    return (ctypes.c_int * len(flat))(*flat), len(flat) // 2
+
+
+class _MSDeformAttn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, value, loc, attw, spatial_shapes):
+        value = _c(value)
+        loc = _c(loc.to(_f32))
+        attw = _c(attw.to(_f32))
+        B, Nv, nH, D = value.shape
+        assert D == 64, 'ge_msda: 64 channels per head'
+        _, Nq, _, L, P, _ = loc.shape
+        arr, nl = _levels(spatial_shapes)
+        assert nl == L
+        out = torch.empty(B, Nq, nH * D, device=value.device, dtype=value.dtype)
+        nbytes = value.numel() * _es(value) + loc.numel() * 4 + attw.numel() * 4 + out.numel() * _es(out)
+        PROFILER.run(f'msda_fwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(
+            hip.lib().ge_msda_fwd(hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), hip.ptr(loc), hip.ptr(attw),
+                                  hip.ptr(out), B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()), 'ge_msda_fwd'))
+        ctx.save_for_backward(value, loc, attw)
+        ctx.shapes = tuple(tuple(int(v) for v in hw) for hw in spatial_shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        value, loc, attw = ctx.saved_tensors
+        B, Nv, nH, D = value.shape
+        _, Nq, _, L, P, _ = loc.shape
+        d_out = _c(d_out.to(value.dtype))
+        arr, _ = _levels(ctx.shapes)
+        d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
+        d_loc = torch.empty_like(loc)
+        d_attw = torch.empty_like(attw)
+        nbytes = (value.numel() * _es(value) + 2 * loc.numel() * 4 + 2 * attw.numel() * 4 + d_out.numel() * _es(d_out)
+                  + d_value.numel() * 4)
+        PROFILER.run(f'msda_bwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(
+            hip.lib().ge_msda_bwd(hip.ptr(value), ctypes.cast(arr, ctypes.c_void_p), hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
+                                  hip.ptr(d_value), hip.ptr(d_loc), hip.ptr(d_attw), B, Nv, Nq, nH, L, P,
+                                  hip.dtype_code(value), hip.stream()), 'ge_msda_bwd'))
+        return d_value.to(value.dtype), d_loc, d_attw, None
+
+
+def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights):
+    """value (B,Nv,nH,64), loc (B,Nq,nH,L,P,2) in [0,1], attw (B,Nq,nH,L,P) -> (B,Nq,nH*64)."""
+    return _MSDeformAttn.apply(value, sampling_locations, attention_weights, spatial_shapes)
+
+
+# -------------------------------------------------------------------------------- bilinear
+class _Bilinear(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align_corners):
+        x = _c(x)
+        N, C, Hi, Wi = x.shape
+        out = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
+        PROFILER.run(f'bilinear_fwd[{N}x{C} {Hi}x{Wi}->{Ho}x{Wo} {_tag(x)}]', (x.numel() + out.numel()) * _es(x), lambda: hip.check(
+            hip.lib().ge_bilinear_fwd(hip.ptr(x, name='input'), hip.ptr(out), N, C, Hi, Wi, Ho, Wo, int(align_corners),
+                                      hip.dtype_code(x), hip.stream()), 'ge_bilinear_fwd'))
+        ctx.geom = (N, C, Hi, Wi, Ho, Wo, int(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        N, C, Hi, Wi, Ho, Wo, ac = ctx.geom
+        d_out = _c(d_out)
+        d_in = torch.empty(N, C, Hi, Wi, device=d_out.device, dtype=d_out.dtype)
+        PROFILER.run(f'bilinear_bwd[{N}x{C} {Hi}x{Wi}<-{Ho}x{Wo} {_tag(d_out)}]', (d_out.numel() + d_in.numel()) * _es(d_out),
+                     lambda: hip.check(hip.lib().ge_bilinear_bwd(hip.ptr(d_out), hip.ptr(d_in), N, C, Hi, Wi, Ho, Wo, ac,
+                                                                 hip.dtype_code(d_out), hip.stream()), 'ge_bilinear_bwd'))
+        return d_in, None, None, None
+
+
+def bilinear_resize(x, size, align_corners=False):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=...) on the HIP kernel."""
+    Ho, Wo = int(size[0]), int(size[1])
+    if x.shape[2] == Ho and x.shape[3] == Wo:
+        return x
+    return _Bilinear.apply(x, Ho, Wo, bool(align_corners))
+
+
+# ------------------------------------------------------------------------ ground embedding
+def _plane_view(img, channel):
+    """(base tensor for the pointer, batch stride in elements) of img[:, channel] (B,5,H,W contiguous)."""
+    if not img.is_cuda:
+        raise RuntimeError('gedepth_amd ops run on MI355X only; got a CPU image tensor')
+    assert img.dim() == 4 and img.is_contiguous() and img.dtype == _f32
+    return img[:, channel], img.stride(0)
+
+
+class _GroundEmbedAdaptive(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, logits_lr, y_lr, img, height, depth_scale):
+        logits_lr = _c(logits_lr.to(_f32))
+        y_lr = _c(y_lr.to(_f32))
+        B, _, h, w = logits_lr.shape
+        H, W = img.shape[2], img.shape[3]
+        pe, bs = _plane_view(img, 4)
+        dev = img.device
+        pe_mask = torch.empty(B, 1, H, W, device=dev, dtype=_f32)
+        logits_hr = torch.empty(B, 11, H, W, device=dev, dtype=_f32)
+        y_hr = torch.empty(B, 1, H, W, device=dev, dtype=_f32)
+        valid = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+        height = None if height is None else _c(height.to(_f32))
+        nbytes = B * H * W * (4 + 4 + 44 + 4 + 1) + B * h * w * 12 * 4
+        PROFILER.run(f'ground_embed_fwd[{B}x{H}x{W}]', nbytes, lambda: hip.check(hip.lib().ge_ground_embed_fwd(
+            hip.ptr(logits_lr), hip.ptr(y_lr), pe.data_ptr(), bs, hip.ptr(height), depth_scale,
+            hip.ptr(pe_mask), hip.ptr(logits_hr), hip.ptr(y_hr), hip.ptr(valid), B, h, w, H, W, hip.stream()),
+            'ge_ground_embed_fwd'))
+        ctx.save_for_backward(logits_lr, y_lr, img, height)
+        ctx.depth_scale = depth_scale
+        ctx.mark_non_differentiable(valid)
+        return pe_mask, logits_hr, y_hr, valid
+
+    @staticmethod
+    def backward(ctx, d_pe_mask, d_logits_hr, d_y_hr, _d_valid):
+        logits_lr, y_lr, img, height = ctx.saved_tensors
+        B, _, h, w = logits_lr.shape
+        H, W = img.shape[2], img.shape[3]
+        pe, bs = _plane_view(img, 4)
+        dev = img.device
+        d_pe_mask = _c(d_pe_mask.to(_f32))
+        d_logits_hr = None if d_logits_hr is None else _c(d_logits_hr.to(_f32))
+        d_y_hr = None if d_y_hr is None else _c(d_y_hr.to(_f32))
+        d_logits_lr = torch.empty_like(logits_lr)
+        d_y_lr = torch.empty_like(y_lr)
+        scratch = torch.empty(B, 12, H, W, device=dev, dtype=_f32)
+        nbytes = B * H * W * (4 + 4 + 44 + 4) + 2 * B * h * w * 12 * 4
+        PROFILER.run(f'ground_embed_bwd[{B}x{H}x{W}]', nbytes, lambda: hip.check(hip.lib().ge_ground_embed_bwd(
+            hip.ptr(logits_lr), hip.ptr(y_lr), pe.data_ptr(), bs, hip.ptr(height), ctx.depth_scale,
+            hip.ptr(d_pe_mask), hip.ptr(d_logits_hr), hip.ptr(d_y_hr), hip.ptr(d_logits_lr), hip.ptr(d_y_lr),
+            hip.ptr(scratch), B, h, w, H, W, hip.stream()), 'ge_ground_embed_bwd'))
+        return d_logits_lr, d_y_lr, None, None, None
+
+
+def ground_embed_adaptive(logits_lr, y_lr, img, height=None, depth_scale=200.0):
+    """-> pe_mask (B,1,H,W), logits_hr (B,11,H,W), y_hr (B,1,H,W), valid_mask u8 (B,H,W)."""
+    return _GroundEmbedAdaptive.apply(logits_lr, y_lr, img, height, float(depth_scale))
+
+
+class _GroundEmbedVanilla(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, y_lr, img, gain):
+        y_lr = _c(y_lr.to(_f32))
+        B, _, h, w = y_lr.shape
+        H, W = img.shape[2], img.shape[3]
+        pe, bs = _plane_view(img, 3)
+        pe_mask = torch.empty(B, 1, H, W, device=img.device, dtype=_f32)
+        y_hr = torch.empty(B, 1, H, W, device=img.device, dtype=_f32)
+        hip.check(hip.lib().ge_ground_vanilla_fwd(hip.ptr(y_lr), pe.data_ptr(), bs, gain, hip.ptr(pe_mask), hip.ptr(y_hr),
+                                                  B, h, w, H, W, hip.stream()), 'ge_ground_vanilla_fwd')
+        ctx.save_for_backward(img)
+        ctx.geom = (B, h, w, H, W, gain)
+        return pe_mask, y_hr
+
+    @staticmethod
+    def backward(ctx, d_pe_mask, d_y_hr):
+        img, = ctx.saved_tensors
+        B, h, w, H, W, gain = ctx.geom
+        pe, bs = _plane_view(img, 3)
+        d_pe_mask = _c(d_pe_mask.to(_f32))
+        d_y_hr = None if d_y_hr is None else _c(d_y_hr.to(_f32))
+        d_y_lr = torch.empty(B, 1, h, w, device=img.device, dtype=_f32)
+        scratch = torch.empty(B, 1, H, W, device=img.device, dtype=_f32)
+        hip.check(hip.lib().ge_ground_vanilla_bwd(pe.data_ptr(), bs, gain, hip.ptr(d_pe_mask), hip.ptr(d_y_hr), hip.ptr(d_y_lr),
+                                                  hip.ptr(scratch), B, h, w, H, W, hip.stream()), 'ge_ground_vanilla_bwd')
+        return d_y_lr, None, None
+
+
+def ground_embed_vanilla(y_lr, img, gain=200.0):
+    """-> pe_mask = img[:,3:4] * up(y) * 200, y_hr."""
+    return _GroundEmbedVanilla.apply(y_lr, img, float(gain))
+
+
+# ----------------------------------------------------------------------------- depth fusion
+class _DepthFuse(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, c, pe_mask, y_hr, min_depth):
+        c = _c(c.to(_f32))
+        pe_mask = _c(pe_mask.to(_f32))
+        y_hr = _c(y_hr.to(_f32))
+        B, _, h, w = c.shape
+        H, W = pe_mask.shape[2], pe_mask.shape[3]
+        out = torch.empty_like(c)
+        y_ds = torch.empty_like(c)
+        hip.check(hip.lib().ge_depth_fuse_fwd(hip.ptr(c), hip.ptr(pe_mask), hip.ptr(y_hr), min_depth, hip.ptr(out), hip.ptr(y_ds),
+                                              B, h, w, H, W, hip.stream()), 'ge_depth_fuse_fwd')
+        ctx.save_for_backward(c, y_ds)
+        ctx.geom = (B, h, w, H, W)
+        ctx.mark_non_differentiable(y_ds)
+        return out, y_ds
+
+    @staticmethod
+    def backward(ctx, d_out, _d_yds):
+        c, y_ds = ctx.saved_tensors
+        B, h, w, H, W = ctx.geom
+        d_out = _c(d_out.to(_f32))
+        d_c = torch.empty_like(c)
+        d_pe = torch.empty(B, 1, H, W, device=c.device, dtype=_f32)
+        d_y = torch.empty(B, 1, H, W, device=c.device, dtype=_f32)
+        scratch = torch.empty(B, 2, h, w, device=c.device, dtype=_f32)
+        hip.check(hip.lib().ge_depth_fuse_bwd(hip.ptr(c), hip.ptr(y_ds), hip.ptr(d_out), hip.ptr(d_c), hip.ptr(d_pe), hip.ptr(d_y),
+                                              hip.ptr(scratch), B, h, w, H, W, hip.stream()), 'ge_depth_fuse_bwd')
+        return d_c, d_pe, d_y, None
+
+
+def depth_fuse(conv_out, pe_mask, y_hr, min_depth):
+    """relu(c)*(1-dn(y)) + dn(pe) + min_depth -> (out, y_ds)."""
+    return _DepthFuse.apply(conv_out, pe_mask, y_hr, float(min_depth))
+
+
+# ------------------------------------------------------------------------------------ SiLog
+class _SiLog(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, pred, gt, eps, loss_weight):
+        pred = _c(pred.to(_f32))
+        gt = _c(gt.to(_f32))
+        stats = torch.zeros(3, device=pred.device, dtype=torch.float64)
+        hip.check(hip.lib().ge_silog_stats(hip.ptr(pred), hip.ptr(gt), eps, hip.ptr(stats), pred.numel(), hip.stream()),
+                  'ge_silog_stats')
+        n, s1, s2 = stats[0], stats[1], stats[2]
+        mean = s1 / n
+        var = (s2 - n * mean * mean) / (n - 1)          # torch.var: unbiased
+        D = torch.sqrt(var + 0.15 * mean * mean)
+        ctx.save_for_backward(pred, gt, n, mean, D)
+        ctx.eps, ctx.w = eps, loss_weight
+        return (loss_weight * D).to(_f32)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, n, mean, D = ctx.saved_tensors
+        k = (g.double() * ctx.w) / (2.0 * D)
+        coef_a = (k * 2.0 / (n - 1)).to(_f32).reshape(1).contiguous()
+        coef_b = (k * (-2.0 * mean / (n - 1) + 0.3 * mean / n)).to(_f32).reshape(1).contiguous()
+        d_pred = torch.empty_like(pred)
+        hip.check(hip.lib().ge_silog_bwd(hip.ptr(pred), hip.ptr(gt), ctx.eps, hip.ptr(coef_a), hip.ptr(coef_b), hip.ptr(d_pred),
+                                         pred.numel(), hip.stream()), 'ge_silog_bwd')
+        return d_pred, None, None, None
+
+
+def silog_loss(pred, gt, eps=1e-3, loss_weight=1.0):
+    """SigLoss with valid_mask = gt > 0, without the boolean gather (no host sync)."""
+    return _SiLog.apply(pred, gt, float(eps), float(loss_weight))
+
+
+# --------------------------------------------------------------------- offline ground maps
+def ground_plane(rinv_row2, num, H, W, device='cuda', want_f64=True):
+    """pe(u,v) = num / (r20 u + r21 v + r22); returns (pe_f64 or None, pe_f32)."""
+    arr = (ctypes.c_double * 3)(*[float(v) for v in rinv_row2])
+    pe64 = torch.empty(H, W, device=device, dtype=torch.float64) if want_f64 else None
+    pe32 = torch.empty(H, W, device=device, dtype=_f32)
+    hip.check(hip.lib().ge_ground_plane(ctypes.cast(arr, ctypes.c_void_p), float(num), hip.ptr(pe64), hip.ptr(pe32), H, W,
+                                        hip.stream()), 'ge_ground_plane')
+    return pe64, pe32
+
+
+def slope_class(gt_f64, pe_f32, cam_height=1.65, mode='round'):
+    gt_f64 = _c(gt_f64.to(torch.float64))
+    pe_f32 = _c(pe_f32.to(_f32))
+    H, W = gt_f64.shape
+    cls = torch.empty(H, W, device=gt_f64.device, dtype=torch.int16)
+    hip.check(hip.lib().ge_slope_class(hip.ptr(gt_f64), hip.ptr(pe_f32), float(cam_height), 0 if mode == 'round' else 1,
+                                       hip.ptr(cls), H, W, hip.stream()), 'ge_slope_class')
+    return cls
+
+
+def pe_channels(raw, depth_scale=200.0):
+    raw = _c(raw.to(_f32))
+    norm = torch.empty_like(raw)
+    hip.check(hip.lib().ge_pe_channels(hip.ptr(raw), hip.ptr(norm), float(depth_scale), raw.numel(), hip.stream()), 'ge_pe_channels')
+    return norm

@@ -1,0 +1,188 @@
+/*
+ * gedepth_hip.h — C ABI of libgedepth_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels
+ * of the GEDepth training hot path.
+ *
+ * The reference (qcraftai/gedepth) has no FFI: these ops replace chains of PyTorch/ATen kernels
+ * and one mmcv CUDA extension.  Each entry point cites the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C"; every function returns 0 on success, otherwise a hipError_t value
+ *     (GE_ERR_* below for argument errors).  Nothing throws, allocates or synchronises.
+ *   - all pointers are DEVICE pointers owned by the caller, contiguous in the documented layout;
+ *   - `stream` is a hipStream_t (pass PyTorch's current stream);
+ *   - `dtype` selects the storage type of the activation tensors: GE_F32 or GE_BF16.
+ *     Accumulation is always fp32.  Bias tables, sampling locations, attention weights and the
+ *     whole ground-embedding path are fp32 regardless;
+ *   - re-entrant: no mutable global state.
+ */
+#ifndef GEDEPTH_HIP_H
+#define GEDEPTH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GE_F32 = 0, GE_BF16 = 1 };
+enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
+
+/* Library / device identification: returns the ABI version (1). */
+int ge_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Swin shifted-window attention core.
+ * Replaces ShiftWindowMSA.forward + WindowMSA.forward between the qkv and proj Linears
+ * (depth/models/backbones/depthformer_swin.py:285-360 and :193-221): zero-pad to a multiple of 7
+ * (after norm1, before qkv => pad tokens carry q=k=v=qkv.bias), roll(-shift), window partition,
+ * q*scale, QK^T, + relative-position bias (index (i_a-i_b+6)*13+(j_a-j_b+6), :166-172), + shift
+ * mask (-100 between regions, :305-326), softmax, AV, window reverse, roll(+shift), crop.
+ *
+ *   qkv        (B, H*W, 3*C)  dtype; last dim ordered [3][nH][32]  (reshape of :193-194)
+ *   qkv_bias   (3*C)          f32   value of q/k/v for pad tokens
+ *   bias_table (169, nH)      f32   relative_position_bias_table
+ *   out        (B, H*W, C)    dtype; channel = head*32 + d  (the transpose(1,2).reshape of :221)
+ * head_dim is fixed at 32 (true for every Swin stage of the reference), window 7, shift in {0,3}.
+ * `variant`: 0 = auto, 1 = exact-fp32 VALU kernel, 2 = bf16 MFMA kernel (dtype must be GE_BF16).
+ */
+int ge_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_table, void* out,
+                       int B, int H, int W, int nH, int shift, float scale, int dtype, int variant,
+                       void* stream);
+
+/* Backward.  d_qkv (B,H*W,3C) dtype is fully written.  d_bias_table (169,nH) f32 and
+ * d_qkv_bias (3C) f32 (pad-token contribution, to be ADDED to the Linear's own bias grad) are
+ * fully written as well (deterministic two-stage reduction through `workspace`).
+ * workspace: at least ge_window_attn_bwd_workspace(...) bytes. */
+size_t ge_window_attn_bwd_workspace(int B, int H, int W, int nH);
+int ge_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias_table, const void* d_out,
+                       void* d_qkv, float* d_qkv_bias, float* d_bias_table, void* workspace,
+                       int B, int H, int W, int nH, int shift, float scale, int dtype, int variant,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention sampling core.
+ * Replaces mmcv.ops.MultiScaleDeformableAttention's ms_deform_attn CUDA op as called from
+ * depth/models/necks/hahi.py:279-289,316-325 (mmcv-full 1.3.13, not vendored): bilinear taps with
+ * zero padding, align_corners=False, weighted sum over levels x points.
+ *
+ *   value          (B, Nv, nH, 64)        dtype   (nH*64 == embed dims; channels per head fixed at 64)
+ *   spatial_hw     host int[2*L]          (H_0,W_0, H_1,W_1, ...)   L <= 8
+ *   loc            (B, Nq, nH, L, P, 2)   f32     normalised (x,y) in [0,1]
+ *   attw           (B, Nq, nH, L, P)      f32
+ *   out            (B, Nq, nH*64)         dtype
+ */
+int ge_msda_fwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, void* out,
+                int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+
+/* Backward.  d_value (B,Nv,nH,64) is ALWAYS f32 and must be zero-filled by the caller (fp32 atomics);
+ * d_loc / d_attw are fully written. */
+int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw,
+                const void* d_out, float* d_value, float* d_loc, float* d_attw,
+                int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear resize (NCHW), both align_corners conventions of F.interpolate, used for every
+ * resize on the path (depth/ops/wrappers.py:7-26; necks/pemask_neck.py:54-61;
+ * decode_heads/densedepth_head.py:26; decode_head.py:492-503,515-520).
+ * Backward is a deterministic gather (no atomics): d_in is fully written.
+ *   in (N, C, Hi, Wi) -> out (N, C, Ho, Wo), dtype storage.
+ */
+int ge_bilinear_fwd(const void* in, void* out, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                    int align_corners, int dtype, void* stream);
+int ge_bilinear_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                    int align_corners, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ground-embedding prior (all fp32).
+ * Adaptive: DepthEncoderDecoder.dynamic_pe + the y up-sampling of extract_feat
+ * (depth/models/depther/encoder_decoder.py:79-102,111-114).  The bilinear (align_corners=False)
+ * up-sampling of the 11 slope logits and of y happens inside the kernel.
+ *   logits_lr (B,11,h,w)   y_lr (B,1,h,w)   pe_raw: B planes of (H,W), plane b at pe_raw + b*pe_batch_stride
+ *   height    (B) or NULL (=> 1.65)          depth_scale (200)
+ * outputs: pe_mask (B,1,H,W)  logits_hr (B,11,H,W)  y_hr (B,1,H,W)  valid_mask u8 (B,H,W) in {0,1}
+ * (valid_mask is the "integer pixel mask" pe_offset_mask of :97-100: bit-exact vs the reference).
+ */
+int ge_ground_embed_fwd(const float* logits_lr, const float* y_lr, const float* pe_raw, long pe_batch_stride,
+                        const float* height, float depth_scale,
+                        float* pe_mask, float* logits_hr, float* y_hr, uint8_t* valid_mask,
+                        int B, int h, int w, int H, int W, void* stream);
+/* Backward: given d_pe_mask (B,1,H,W), d_logits_hr (B,11,H,W) (may be NULL), d_y_hr (B,1,H,W) (may be
+ * NULL) produce d_logits_lr (B,11,h,w) and d_y_lr (B,1,h,w) (both fully written).
+ * scratch: (B,12,H,W) f32 of caller-owned scratch. */
+int ge_ground_embed_bwd(const float* logits_lr, const float* y_lr, const float* pe_raw, long pe_batch_stride,
+                        const float* height, float depth_scale,
+                        const float* d_pe_mask, const float* d_logits_hr, const float* d_y_hr,
+                        float* d_logits_lr, float* d_y_lr, float* scratch,
+                        int B, int h, int w, int H, int W, void* stream);
+
+/* Vanilla: pe_mask = img[:,3:4] * up(y) * 200  (encoder_decoder.py:111-114,120-123).
+ *   pe_norm: B planes (H,W) at pe_norm + b*pe_batch_stride. */
+int ge_ground_vanilla_fwd(const float* y_lr, const float* pe_norm, long pe_batch_stride, float gain,
+                          float* pe_mask, float* y_hr, int B, int h, int w, int H, int W, void* stream);
+int ge_ground_vanilla_bwd(const float* pe_norm, long pe_batch_stride, float gain,
+                          const float* d_pe_mask, const float* d_y_hr, float* d_y_lr, float* scratch,
+                          int B, int h, int w, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Depth fusion (fp32):  out = relu(c)*(1 - dn(y)) + dn(pe) + min_depth, where dn() is the
+ * align_corners=True bilinear resize (H,W)->(h,w) of DepthBaseDecodeHead.depth_pred
+ * (depth/models/decode_heads/decode_head.py:489-506).
+ *   c (B,1,h,w) conv_depth output BEFORE ReLU;  pe_mask, y_hr (B,1,H,W);  out, y_ds (B,1,h,w).
+ */
+int ge_depth_fuse_fwd(const float* c, const float* pe_mask, const float* y_hr, float min_depth,
+                      float* out, float* y_ds, int B, int h, int w, int H, int W, void* stream);
+/* d_c (B,1,h,w), d_pe_mask (B,1,H,W), d_y_hr (B,1,H,W) fully written. scratch: (B,2,h,w) f32. */
+int ge_depth_fuse_bwd(const float* c, const float* y_ds, const float* d_out,
+                      float* d_c, float* d_pe_mask, float* d_y_hr, float* scratch,
+                      int B, int h, int w, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Offline ground-plane maps (fp64 arithmetic, as numpy does in the reference).
+ * ge_ground_plane: pe(u,v) = num / (r20*u + r21*v + r22)  (tools/preprocess_data_kitti.py:47-53),
+ *   rinv_row2 = host double[3], num = RT[2]-cam_height.  pe_f64 (H,W) and/or pe_f32 (H,W) (either
+ *   may be NULL; the f32 copy is the astype(np.float32) of datasets/pipelines/loading.py:375).
+ * ge_slope_class: k = h/gt + f32(-h)/pe; round (mode 0, KITTI :59-63,83-89) or trunc (mode 1, DDAD
+ *   tools/preprocess_data_ddad.py:78) of deg(atan k), clamp to [-5,5], 255 where gt==0.
+ *   gt f64 (H,W) [uint16 PNG / 256], pe f32 (H,W) -> cls int16 (H,W).
+ * ge_pe_channels: loader-side filtering + normalisation (loading.py:397-403, transforms.py:40-48):
+ *   raw f32 -> norm f32 (>200 -> 0, <0 -> 0, then / depth_scale where > 0).
+ */
+int ge_ground_plane(const double* rinv_row2, double num, double* pe_f64, float* pe_f32, int H, int W,
+                    void* stream);
+int ge_slope_class(const double* gt, const float* pe, double cam_height, int mode, int16_t* cls,
+                   int H, int W, void* stream);
+int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SiLog loss statistics (fp32 in, fp64 accumulate), SigLoss.sigloss
+ * (depth/models/losses/sigloss.py:36-53) without the dynamic-shape boolean gather:
+ * over valid = gt > 0:  stats[0] = n, stats[1] = sum g, stats[2] = sum g^2 with
+ * g = log(pred+eps) - log(gt+eps).  `stats` (3 doubles) must be zeroed by the caller.
+ * Backward: d_pred = valid ? coef_a[0] * g + coef_b[0] : 0, divided by (pred+eps); coef_* are
+ * device scalars computed by the host wrapper from the statistics (no host sync). */
+int ge_silog_stats(const float* pred, const float* gt, float eps, double* stats, long n, void* stream);
+int ge_silog_bwd(const float* pred, const float* gt, float eps, const float* coef_a, const float* coef_b,
+                 float* d_pred, long n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter arena (torch.optim.AdamW semantics as configured by
+ * configs/depthformer/depthformer_v.py:128-140 through mmcv's DefaultOptimizerConstructor) with the
+ * L2 gradient clip of OptimizerHook(grad_clip=dict(max_norm=35)) folded in.
+ *   ge_sumsq: out[0] += sum(x^2) (fp64; caller zeroes `out`).
+ *   ge_adamw_step: for i<n: g = grad[i]*min(1, max_norm/(sqrt(gnorm_sq[0])+1e-6));
+ *       p *= 1 - lr*wd[seg(i)];  m,v updates;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ *     decay is per element via `wd_mask` (u8: 1 = apply weight decay) to honour paramwise decay_mult=0.
+ *     lr / step-dependent scalars are read from a small device array `hyper` =
+ *     {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm} so that the launch can
+ *     be captured in a hipGraph and replayed while the host updates `hyper`.
+ */
+int ge_sumsq(const float* x, long n, double* out, void* stream);
+int ge_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* wd_mask,
+                  const float* hyper, const double* gnorm_sq, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEDEPTH_HIP_H */

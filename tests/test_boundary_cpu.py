@@ -1,0 +1,149 @@
+"""Drop-in boundary, host side (no GPU): config loader, registry/build protocol, state-dict schema,
+C-ABI library exports.  SURVEY.md §8(b)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from gedepth_amd import hip
+from gedepth_amd.depth.models import MODELS, build_depther
+from gedepth_amd.mmrt.config import Config, DictAction
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+REGISTRY_NAMES = ['DepthEncoderDecoder', 'DepthFormerSwin', 'HAHIHeteroNeck', 'LightPEMASKNeck', 'DynamicPENeckSOFT',
+                  'DenseDepthHead', 'SigLoss', 'CrossEntropyLoss', 'BinaryCrossEntropyLoss']
+
+
+def cfg_path(name):
+    return os.path.join(ROOT, 'configs', 'depthformer', name)
+
+
+def test_registry_names():
+    for n in REGISTRY_NAMES:
+        assert MODELS.get(n) is not None, n
+    from gedepth_amd.mmrt.bricks import POSITIONAL_ENCODING
+    assert POSITIONAL_ENCODING.get('SinePositionalEncoding') is not None
+
+
+def test_config_inheritance_and_delete():
+    cfg = Config.fromfile(cfg_path('depthformer_a.py'))
+    assert cfg.model.backbone.embed_dims == 192 and cfg.model['backbone']['depths'] == [2, 2, 18, 2]
+    assert cfg.model.dynamic_pe_neck.type == 'DynamicPENeckSOFT'
+    assert cfg.model.backbone.drop_path_rate == 0.3             # inherited from the base
+    assert [h['type'] for h in cfg.log_config.hooks] == ['TextLoggerHook', 'TensorboardLoggerHook']  # _delete_
+    assert cfg.log_config.interval == 10
+    assert cfg.lr_config.warmup_iters == 25600 and cfg.runner.max_iters == 76800
+    cfg.merge_from_dict(DictAction.parse(['model.backbone.drop_path_rate=0.1', 'data.samples_per_gpu=4']))
+    assert cfg.model.backbone.drop_path_rate == 0.1 and cfg.data.samples_per_gpu == 4
+    assert 'model = dict(' in cfg.pretty_text
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+@pytest.mark.parametrize('name', ['depthformer_v.py', 'depthformer_a.py'])
+def test_reference_configs_load_unchanged_and_resolve_identically(name):
+    """The reference's own config files load byte-unchanged through our loader, and our re-structured
+    configs resolve to the same model / optimizer / schedule."""
+    ref = Config.fromfile(os.path.join(REF, 'configs', 'depthformer', name))
+    ours = Config.fromfile(cfg_path(name))
+    for key in ['model', 'optimizer', 'optimizer_config', 'lr_config', 'runner', 'checkpoint_config', 'evaluation',
+                'log_config', 'dist_params', 'workflow', 'data']:
+        assert ref.to_dict()[key] == ours.to_dict()[key], key
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
+def test_reference_ddad_configs_load():
+    for name in ['depthformer_v_ddad.py', 'depthformer_a_ddad.py']:
+        cfg = Config.fromfile(os.path.join(REF, 'configs', 'depthformer', name))
+        assert cfg.model.type == 'DepthEncoderDecoder'
+
+
+def _build(name, **over):
+    cfg = Config.fromfile(cfg_path(name))
+    cfg.model.pretrained = None
+    for k, v in over.items():
+        cfg.model[k] = v
+    return build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+
+
+@pytest.mark.parametrize('cfg_name,fixture', [('depthformer_swint_v.py', 'e2e_T_V'), ('depthformer_swint_a.py', 'e2e_T_A'),
+                                              ('depthformer_a.py', 'e2e_L_A')])
+def test_state_dict_schema_matches_reference(cfg_name, fixture, golden):
+    """Key names, order-insensitive, shapes and dtypes equal the state dict captured from the reference
+    (516 entries for Swin-L-A)."""
+    model = _build(cfg_name)
+    spec = {k: tuple(s) for k, s in json.loads(str(golden(fixture)['spec']))}
+    ours = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert set(ours) == set(spec), (sorted(set(ours) ^ set(spec))[:10])
+    assert ours == spec
+    if fixture == 'e2e_L_A':
+        assert len(ours) == 516
+    n_params = sum(p.numel() for p in model.parameters())
+    assert n_params == sum(int(np.prod(spec[k])) for k, _ in model.named_parameters())
+
+
+def test_build_depther_contract():
+    cfg = Config.fromfile(cfg_path('depthformer_swint_v.py'))
+    cfg.model.pretrained = None
+    with pytest.raises(AssertionError):
+        build_depther(cfg.model, train_cfg=dict())          # given twice
+    with pytest.raises(KeyError):
+        build_depther(dict(type='NoSuchDepther'))
+    m = build_depther(cfg.model)
+    assert m.test_cfg.mode == 'whole' and m.align_corners is True
+    assert not m.dynamic_pe_neck_FLAGS and m.pe_mask_neck_FLAGS
+    with pytest.raises(TypeError):
+        m.forward_test(torch.zeros(1), [[]])                 # imgs must be a list (depther/base.py:74-77)
+    with pytest.raises(ValueError):
+        m.forward_test([torch.zeros(1)], [[], []])
+
+
+def test_pretrained_pushed_into_backbone():
+    cfg = Config.fromfile(cfg_path('depthformer_v.py'))
+    assert cfg.model.pretrained.endswith('.pth')
+    cfg.model.backbone.depths = [1, 1, 1, 1]
+    m = build_depther(cfg.model)
+    assert m.backbone.pretrained == cfg.model.pretrained
+
+
+def test_init_weights_runs_and_is_deterministic_under_seed():
+    torch.manual_seed(0)
+    m = _build('depthformer_swint_a.py')
+    m.init_weights()
+    sd = m.state_dict()
+    assert torch.count_nonzero(sd['neck.multi_att.sampling_offsets.weight']) == 0
+    assert torch.count_nonzero(sd['neck.multi_att.attention_weights.bias']) == 0
+    b = sd['neck.self_attn.sampling_offsets.bias'].view(8, 4, 8, 2)
+    assert torch.allclose(b[0, 0, :, 0], torch.arange(1, 9.0)) and torch.allclose(b[0, 0, :, 1], torch.zeros(8), atol=1e-6)
+    t = sd['backbone.stages.0.blocks.0.attn.w_msa.relative_position_bias_table']
+    assert 0.005 < t.std() < 0.04
+
+
+def test_cpu_tensors_fail_loudly():
+    """There is no CPU/eager fallback in the product path."""
+    from gedepth_amd.kernels import bilinear_resize, window_attention
+    if not hip.is_built():
+        pytest.skip('library not built')
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        bilinear_resize(torch.zeros(1, 1, 4, 4), (8, 8))
+    with pytest.raises(RuntimeError, match='MI355X only'):
+        window_attention(torch.zeros(1, 49, 288), torch.zeros(288), torch.zeros(169, 3), 7, 7, 3, 0, 0.17)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'gedepth_hip.h')).read()
+    declared = set(re.findall(r'\b(ge_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    if not hip.is_built():
+        pytest.fail(f'{hip.LIB_PATH} missing: run gedepth_amd/csrc/build.sh')
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.lib().ge_abi_version() == 1
+    # argument validation happens before any launch, so these are safe without a GPU
+    assert hip.lib().ge_bilinear_fwd(None, None, 1, 1, 4, 4, 8, 8, 0, 0, None) == 10001
+    assert hip.lib().ge_window_attn_bwd_workspace(2, 11, 35, 3) > 0

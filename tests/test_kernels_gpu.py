@@ -1,0 +1,429 @@
+"""Parity of every HIP kernel (through the C ABI / autograd wrappers) against the CPU oracle, the
+golden fixtures generated from the reference, and size-independent properties.  Runs on MI355X only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import gedepth_oracle as O
+from oracle.fill import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5        # fp32: BASELINE.json north_star "within 1e-4 rel fp32"
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from gedepth_amd import hip
+    hip.lib()                   # fail loudly if the native library is missing
+    return torch.device('cuda:0')
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, what=''):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bool(bad.any()), (f'{what}: {int(bad.sum())}/{bad.numel()} off; max abs err {err.max():.3e} '
+                                 f'(ref scale {b.abs().max():.3e})')
+
+
+def close_scaled(a, b, rel=1e-4, what=''):
+    """Gradient comparison: error relative to the tensor's max magnitude."""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, f'{what}: max abs err {err:.3e} vs scale {scale:.3e}'
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ====================================================================== window attention
+def _attn_weights(C, nH, salt='t'):
+    names = [('a.w_msa.relative_position_bias_table', (169, nH)), ('a.w_msa.qkv.weight', (3 * C, C)),
+             ('a.w_msa.qkv.bias', (3 * C,)), ('a.w_msa.proj.weight', (C, C)), ('a.w_msa.proj.bias', (C,))]
+    return fill_state_dict(names, salt)
+
+
+def _product_attn(C, nH, shift, P, dev, variant=0):
+    from gedepth_amd.depth.models.backbones.depthformer_swin import ShiftWindowMSA
+    m = ShiftWindowMSA(C, nH, 7, shift_size=shift, dropout_layer=dict(type='DropPath', drop_prob=0.))
+    m.load_state_dict({k[2:]: v for k, v in P.items()}, strict=False)
+    m.kernel_variant = variant
+    return m.to(dev)
+
+
+@pytest.mark.parametrize('hw', [(11, 35), (10, 9), (14, 14), (7, 7), (3, 5)])
+@pytest.mark.parametrize('shift', [0, 3])
+def test_window_attention_fp32_fwd_bwd(dev, hw, shift):
+    C, nH, B = 96, 3, 2
+    H, W = hw
+    P = _attn_weights(C, nH)
+    x = torch.randn(B, H * W, C, generator=gen(H * 100 + W + shift))
+    go = torch.randn(B, H * W, C, generator=gen(7))
+    # oracle (CPU autograd)
+    Pc = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xc = x.clone().requires_grad_(True)
+    ref = O.shift_window_msa(xc, hw, Pc, 'a', nH, shift)
+    ref.backward(go)
+    # product (HIP)
+    m = _product_attn(C, nH, shift, P, dev, variant=1)
+    xg = x.to(dev).requires_grad_(True)
+    out = m(xg, hw)
+    out.backward(go.to(dev))
+    close(out, ref, what='out')
+    close_scaled(xg.grad, xc.grad, what='dx')
+    close_scaled(m.w_msa.qkv.weight.grad, Pc['a.w_msa.qkv.weight'].grad, what='dWqkv')
+    close_scaled(m.w_msa.qkv.bias.grad, Pc['a.w_msa.qkv.bias'].grad, what='dbqkv (incl. pad tokens)')
+    close_scaled(m.w_msa.relative_position_bias_table.grad, Pc['a.w_msa.relative_position_bias_table'].grad,
+                 what='d bias table')
+
+
+@pytest.mark.parametrize('tag,hw', [('a', (11, 35)), ('b', (10, 9))])
+@pytest.mark.parametrize('shift', [0, 3])
+def test_window_attention_golden(dev, golden, tag, hw, shift):
+    """Directly against outputs of the reference's ShiftWindowMSA (tests/golden/shift_window_msa.npz)."""
+    g = golden('shift_window_msa')
+    spec = json.loads(str(g['spec']))
+    P = {'a.' + k: v for k, v in fill_state_dict([(n, s) for n, s in spec], 'shift_window_msa').items()}
+    m = _product_attn(96, 3, shift, P, dev, variant=1)
+    out = m(T(g[f'x_{tag}{shift}']).to(dev), hw)
+    close(out, g[f'out_{tag}{shift}'], what='vs reference')
+
+
+@pytest.mark.parametrize('shift', [0, 3])
+def test_window_attention_bf16_storage(dev, shift):
+    """bf16 storage / fp32 accumulate: compare with the oracle evaluated on the bf16-rounded qkv."""
+    from gedepth_amd.kernels import window_attention
+    B, H, W, nH = 2, 11, 20, 6
+    C = nH * 32
+    qkv = torch.randn(B, H * W, 3 * C, generator=gen(3)).bfloat16()
+    qb = (0.1 * torch.randn(3 * C, generator=gen(4)))
+    tab = 0.5 * torch.randn(169, nH, generator=gen(5))
+    go = torch.randn(B, H * W, C, generator=gen(6)).bfloat16()
+
+    def run(dt, variant):
+        q = qkv.to(dev).to(dt).requires_grad_(True)
+        b = qb.to(dev).requires_grad_(True)
+        t = tab.to(dev).requires_grad_(True)
+        o = window_attention(q, b if dt == torch.float32 else b, t, H, W, nH, shift, 32 ** -0.5, variant)
+        o.backward(go.to(dev).to(dt))
+        return o.float(), q.grad.float(), b.grad, t.grad
+
+    # fp32 run on the same (bf16-representable) inputs, pad value rounded the same way
+    qb_r = qb.bfloat16().float()
+    q32 = qkv.float().to(dev).requires_grad_(True)
+    b32 = qb_r.to(dev).requires_grad_(True)
+    t32 = tab.to(dev).requires_grad_(True)
+    o32 = window_attention(q32, b32, t32, H, W, nH, shift, 32 ** -0.5, 1)
+    o32.backward(go.float().to(dev))
+    o, dq, db, dt_ = run(torch.bfloat16, 1)
+    close(o, o32, rtol=1e-2, atol=1e-2, what='bf16 out')
+    close_scaled(dq, q32.grad, rel=2e-2, what='bf16 dqkv')
+    close_scaled(dt_, t32.grad, rel=1e-3, what='bf16 dtable')
+    close_scaled(db, b32.grad, rel=1e-3, what='bf16 dbias')
+
+
+def test_window_attention_pad_tokens_are_live(dev):
+    """attention over an 11-row map == attention over the same map zero-extended to 14 rows
+    (pad tokens act as keys/values equal to the qkv bias, they are not masked)."""
+    C, nH = 96, 3
+    P = _attn_weights(C, nH)
+    for shift in (0, 3):
+        m = _product_attn(C, nH, shift, P, dev, variant=1)
+        x = torch.randn(1, 11 * 35, C, generator=gen(9)).to(dev)
+        x14 = torch.cat([x.view(1, 11, 35, C), torch.zeros(1, 3, 35, C, device=dev)], 1).view(1, 14 * 35, C)
+        a = m(x, (11, 35))
+        b = m(x14, (14, 35)).view(1, 14, 35, C)[:, :11].reshape(1, 11 * 35, C)
+        assert torch.equal(a, b)
+
+
+# ================================================================================== MSDA
+def _msda_inputs(seed, B=2, Nq=70, shapes=((11, 35), (6, 18), (3, 9), (2, 5))):
+    g = gen(seed)
+    nv = sum(h * w for h, w in shapes)
+    value = torch.randn(B, nv, 8, 64, generator=g)
+    loc = torch.rand(B, Nq, 8, 4, 8, 2, generator=g) * 1.3 - 0.15        # includes out-of-range samples
+    aw = torch.rand(B, Nq, 8, 4, 8, generator=g).flatten(-2).softmax(-1).view(B, Nq, 8, 4, 8)
+    go = torch.randn(B, Nq, 512, generator=g)
+    return value, loc, aw, go, [tuple(s) for s in shapes]
+
+
+def test_msda_fp32_fwd_bwd(dev):
+    from gedepth_amd.kernels import ms_deform_attn
+    value, loc, aw, go, shapes = _msda_inputs(1)
+    vc, lc, ac = (t.clone().requires_grad_(True) for t in (value, loc, aw))
+    ref = O.msda_core(vc, shapes, lc, ac)
+    ref.backward(go)
+    vg, lg, ag = (t.to(dev).requires_grad_(True) for t in (value, loc, aw))
+    out = ms_deform_attn(vg, shapes, lg, ag)
+    out.backward(go.to(dev))
+    close(out, ref, what='out')
+    close_scaled(vg.grad, vc.grad, what='d value')
+    close_scaled(ag.grad, ac.grad, what='d attw')
+    close_scaled(lg.grad, lc.grad, rel=2e-4, what='d loc')
+
+
+def test_msda_golden(dev, golden):
+    from gedepth_amd.kernels import ms_deform_attn
+    g = golden('msda_core')
+    shapes = [tuple(int(v) for v in s) for s in g['shapes']]
+    out = ms_deform_attn(T(g['value']).to(dev), shapes, T(g['loc']).to(dev), T(g['aw']).to(dev))
+    close(out, g['out'], what='vs mmcv-semantics fixture')
+
+
+def test_msda_bf16(dev):
+    from gedepth_amd.kernels import ms_deform_attn
+    value, loc, aw, go, shapes = _msda_inputs(2)
+    vb = value.bfloat16()
+    ref = O.msda_core(vb.float(), shapes, loc, aw)
+    vg = vb.to(dev).requires_grad_(True)
+    lg, ag = loc.to(dev).requires_grad_(True), aw.to(dev).requires_grad_(True)
+    out = ms_deform_attn(vg, shapes, lg, ag)
+    assert out.dtype == torch.bfloat16
+    close(out.float(), ref, rtol=1e-2, atol=1e-2, what='bf16 out')
+    out.backward(go.bfloat16().to(dev))
+    assert vg.grad.dtype == torch.bfloat16 and torch.isfinite(vg.grad.float()).all()
+
+
+def test_msda_module_golden(dev, golden):
+    """Whole MultiScaleDeformableAttention module vs the fixture (mmcv 1.3.13 semantics, dropout off)."""
+    from gedepth_amd.depth.models.necks.hahi import MultiScaleDeformableAttention
+    g = golden('msda_module')
+    spec = json.loads(str(g['spec']))
+    m = MultiScaleDeformableAttention(embed_dims=512, num_levels=4, num_heads=8, num_points=8, batch_first=True)
+    m.load_state_dict(fill_state_dict([(n, s) for n, s in spec], 'msda_module'))
+    m = m.to(dev).eval()
+    shapes = [tuple(int(v) for v in s) for s in g['shapes']]
+    out = m(T(g['q']).to(dev), value=T(g['v']).to(dev), query_pos=T(g['qp']).to(dev),
+            reference_points=T(g['ref']).to(dev), spatial_shapes=shapes)
+    close(out, g['out'], rtol=2e-4, atol=2e-5, what='module')
+
+
+# ============================================================================== bilinear
+@pytest.mark.parametrize('align', [False, True])
+@pytest.mark.parametrize('sizes', [((11, 35), (22, 70)), ((22, 70), (11, 35)), ((7, 9), (16, 31)), ((16, 31), (7, 9)),
+                                   ((5, 6), (5, 6)), ((1, 2), (8, 12)), ((176, 560), (352, 1120))])
+def test_bilinear_fwd_bwd(dev, align, sizes):
+    from gedepth_amd.kernels import bilinear_resize
+    (hi, wi), (ho, wo) = sizes
+    x = torch.randn(2, 3, hi, wi, generator=gen(hi + wo))
+    go = torch.randn(2, 3, ho, wo, generator=gen(5))
+    xc = x.clone().requires_grad_(True)
+    ref = F.interpolate(xc, size=(ho, wo), mode='bilinear', align_corners=align)
+    ref.backward(go)
+    xg = x.to(dev).requires_grad_(True)
+    out = bilinear_resize(xg, (ho, wo), align)
+    if out is xg:
+        return
+    out.backward(go.to(dev))
+    close(out, ref, rtol=1e-5, atol=1e-6, what='fwd')
+    close(xg.grad, xc.grad, rtol=1e-4, atol=1e-5, what='bwd (deterministic gather)')
+
+
+def test_bilinear_bwd_is_deterministic_and_adjoint(dev):
+    """<up(x), g> == <x, up^T(g)> and bit-identical across runs (no atomics)."""
+    from gedepth_amd.kernels import bilinear_resize
+    x = torch.randn(4, 8, 88, 280, device=dev, requires_grad=True)
+    g = torch.randn(4, 8, 176, 560, device=dev)
+    y = bilinear_resize(x, (176, 560), True)
+    y.backward(g)
+    g1 = x.grad.clone()
+    x.grad = None
+    bilinear_resize(x, (176, 560), True).backward(g)
+    assert torch.equal(g1, x.grad)
+    lhs, rhs = (y.detach().double() * g.double()).sum(), (x.detach().double() * g1.double()).sum()
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+
+
+# ====================================================================== ground embedding
+def _ground_inputs(B, H, W, seed):
+    g = gen(seed)
+    h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    img = torch.zeros(B, 5, H, W)
+    img[:, :3] = torch.randn(B, 3, H, W, generator=g)
+    v = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(B, H, W) * (352.0 / H)
+    pe = 1.65 * 721.5377 / (v - 172.854) + 0.05 * torch.randn(B, H, W, generator=g)
+    img[:, 4] = pe
+    img[:, 3] = torch.where((pe > 0) & (pe <= 200), pe, torch.zeros_like(pe)) / 200.0
+    logits = 2.0 * torch.randn(B, 11, h, w, generator=g)
+    y = torch.rand(B, 1, h, w, generator=g)
+    return img, logits, y
+
+
+def _oracle_adaptive(img, logits_lr, y_lr, height):
+    y = F.interpolate(y_lr, size=img.shape[2:], mode='bilinear')
+    pe_mask, logits_hr, m = O.dynamic_pe(logits_lr, y, img[:, 4], 1.65 if height is None else height)
+    off_den = None
+    return pe_mask, logits_hr, y, m
+
+
+@pytest.mark.parametrize('hw', [(24, 40), (33, 47), (352, 1120)])
+@pytest.mark.parametrize('use_height', [False, True])
+def test_ground_embed_adaptive(dev, hw, use_height):
+    from gedepth_amd.kernels import ground_embed_adaptive
+    B = 2
+    img, logits, y = _ground_inputs(B, *hw, seed=hw[0])
+    height = torch.tensor([1.56, 1.53]) if use_height else None
+    lc, yc = logits.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    pe_ref, lg_ref, y_ref, m_ref = _oracle_adaptive(img, lc, yc, height)
+    g = gen(3)
+    g_pe, g_lg, g_y = (torch.randn(t.shape, generator=g) for t in (pe_ref, lg_ref, y_ref))
+    # pixels whose validity is numerically ambiguous (offset within 1e-4 rel of the 200 m threshold or ~0)
+    with torch.no_grad():
+        hh = 1.65 if height is None else height.view(-1, 1, 1, 1)
+        k = torch.tan(torch.deg2rad((F.softmax(lg_ref, 1) * torch.linspace(-5, 5, 11).view(1, 11, 1, 1)).sum(1, keepdim=True)))
+        off = -hh / ((-hh / (img[:, 4:5] + 1e-8) - k) + 1e-8)
+        ambiguous = ((off - 200.0).abs() < 2e-2) | (off.abs() < 1e-6) | ~torch.isfinite(off)
+    (pe_ref * g_pe).sum().backward(retain_graph=True)
+    (lg_ref * g_lg).sum().backward(retain_graph=True)
+    (y_ref * g_y).sum().backward()
+
+    lg_, yg_ = logits.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    pe, lg_hr, y_hr, valid = ground_embed_adaptive(lg_, yg_, img.to(dev), None if height is None else height.to(dev), 200.0)
+    ((pe * g_pe.to(dev)).sum() + (lg_hr * g_lg.to(dev)).sum() + (y_hr * g_y.to(dev)).sum()).backward()
+
+    # integer pixel mask: BIT-EXACT outside the numerically ambiguous set, which must be (almost) empty
+    mism = (valid.cpu().bool() != (m_ref[:, 0] == 1)) & ~ambiguous[:, 0]
+    assert int(mism.sum()) == 0, f'{int(mism.sum())} mask pixels differ'
+    assert int(ambiguous.sum()) <= max(4, ambiguous.numel() // 50000), int(ambiguous.sum())
+    assert valid.dtype == torch.uint8 and set(valid.unique().tolist()) <= {0, 1}
+    close(lg_hr, lg_ref, rtol=1e-5, atol=1e-6, what='logits_hr')
+    close(y_hr, y_ref, rtol=1e-5, atol=1e-6, what='y_hr')
+    ok = ~ambiguous
+    close(pe.cpu()[ok], pe_ref[ok], atol=1e-4, what='pe_mask')
+    close_scaled(lg_.grad, lc.grad, rel=5e-4, what='d logits_lr')
+    close_scaled(yg_.grad, yc.grad, rel=1e-4, what='d y_lr')
+
+
+def test_ground_embed_golden(dev, golden):
+    """Against DepthEncoderDecoder.dynamic_pe of the reference itself."""
+    from gedepth_amd.kernels import ground_embed_adaptive, ground_embed_vanilla
+    g = golden('dynamic_pe')
+    img = T(g['img']).to(dev)
+    # the fixture's y is already at image resolution; feed it as a same-size "low-res" map (identity resize)
+    y = T(g['y']).to(dev)
+    pe, lg_hr, y_hr, valid = ground_embed_adaptive(T(g['logits_lr']).to(dev), y, img, None, 200.0)
+    close(lg_hr, g['logits_hr'], rtol=1e-5, atol=1e-6, what='logits')
+    close(pe, g['pe_mask'], atol=1e-4, what='pe_mask')
+    pe_h, _, _, _ = ground_embed_adaptive(T(g['logits_lr']).to(dev), y, img, T(g['heights']).to(dev), 200.0)
+    close(pe_h, g['pe_mask_h'], atol=1e-4, what='pe_mask (per-sample heights)')
+    pv, _ = ground_embed_vanilla(y, img, 200.0)
+    close(pv, g['vanilla'], what='vanilla')
+
+
+def test_ground_embed_vanilla_bwd(dev):
+    from gedepth_amd.kernels import ground_embed_vanilla
+    img, _, y = _ground_inputs(2, 30, 52, seed=8)
+    yc = y.clone().requires_grad_(True)
+    yu = F.interpolate(yc, size=img.shape[2:], mode='bilinear')
+    ref = O.vanilla_pe(yu, img[:, 3])
+    g = gen(1)
+    g1, g2 = torch.randn(ref.shape, generator=g), torch.randn(ref.shape, generator=g)
+    ((ref * g1).sum() + (yu * g2).sum()).backward()
+    yg = y.to(dev).requires_grad_(True)
+    pe, yh = ground_embed_vanilla(yg, img.to(dev), 200.0)
+    ((pe * g1.to(dev)).sum() + (yh * g2.to(dev)).sum()).backward()
+    close(pe, ref, what='pe_mask')
+    close_scaled(yg.grad, yc.grad, what='d y_lr')
+
+
+def test_depth_fuse(dev):
+    from gedepth_amd.kernels import depth_fuse
+    B, h, w, H, W = 2, 20, 31, 40, 62
+    g = gen(2)
+    c = torch.randn(B, 1, h, w, generator=g)
+    pe = torch.rand(B, 1, H, W, generator=g) * 50
+    y = torch.rand(B, 1, H, W, generator=g)
+    go = torch.randn(B, 1, h, w, generator=g)
+    cc, pc, yc = (t.clone().requires_grad_(True) for t in (c, pe, y))
+    d = F.relu(cc)
+    ref = (d * (1 - F.interpolate(yc, size=(h, w), mode='bilinear', align_corners=True))
+           + F.interpolate(pc, size=(h, w), mode='bilinear', align_corners=True)) + 1e-3
+    ref.backward(go)
+    cg, pg, yg = (t.to(dev).requires_grad_(True) for t in (c, pe, y))
+    out, _ = depth_fuse(cg, pg, yg, 1e-3)
+    out.backward(go.to(dev))
+    close(out, ref, what='out')
+    close_scaled(cg.grad, cc.grad, what='d conv')
+    close_scaled(pg.grad, pc.grad, what='d pe_mask')
+    close_scaled(yg.grad, yc.grad, what='d y')
+
+
+def test_silog(dev, golden):
+    from gedepth_amd.kernels import silog_loss
+    g = golden('known_answers')
+    out = silog_loss(T(g['sig_pred']).to(dev).view(1, 1, 2, 4), T(g['sig_gt']).to(dev).view(1, 1, 2, 4))
+    assert abs(out.item() - 0.28163391) < 1e-6
+    gg = gen(4)
+    pred = torch.rand(2, 1, 64, 96, generator=gg) * 80 + 0.1
+    gt = torch.where(torch.rand(2, 1, 64, 96, generator=gg) < 0.3, torch.rand(2, 1, 64, 96, generator=gg) * 80, torch.zeros(2, 1, 64, 96))
+    pc = pred.clone().requires_grad_(True)
+    ref = O.sigloss(pc, gt)
+    ref.backward()
+    pg = pred.to(dev).requires_grad_(True)
+    out = silog_loss(pg, gt.to(dev))
+    out.backward()
+    close(out, ref, rtol=1e-5, what='loss')
+    close_scaled(pg.grad, pc.grad, what='d pred')
+
+
+# ============================================================== offline ground-plane maps
+def test_ground_plane_and_slope_class_bit_exact(dev):
+    from gedepth_amd.kernels import ground_plane, pe_channels, slope_class
+    P2 = np.array([[7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01], [0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01],
+                   [0.0, 0.0, 1.0, 2.745884e-03]])
+    Tr = np.array([[0., -1, 0, 0], [0, 0, -1, -0.08], [1, 0, 0, -0.27], [0, 0, 0, 1]])
+    H, W = 375, 1242
+    pe_ref, r2, num = O.ground_plane(P2, np.eye(3), Tr, H, W)
+    pe64, pe32 = ground_plane(r2, num, H, W, device=dev)
+    assert np.array_equal(pe64.cpu().numpy(), pe_ref)                        # float64, bit-exact
+    assert np.array_equal(pe32.cpu().numpy(), pe_ref.astype(np.float32))
+    np.testing.assert_allclose(pe64[374, 621].item(), 5.630516794, rtol=1e-9)
+    rs = np.random.RandomState(0)
+    gt = np.where(rs.rand(H, W) < 0.2, np.round(rs.rand(H, W) * 80 * 256) / 256.0, 0.0)
+    for mode in ('round', 'trunc'):
+        k_ref = O.slope_class(gt, pe_ref.astype(np.float32), 1.65, mode)
+        k = slope_class(torch.from_numpy(gt).to(dev), pe32, 1.65, mode).cpu().numpy()
+        assert k.dtype == np.int16
+        assert np.array_equal(k.astype(np.float64), k_ref), int((k != k_ref).sum())
+    norm_ref, raw_ref = O.loader_pe_channels(pe_ref)
+    assert np.array_equal(pe_channels(pe32).cpu().numpy(), norm_ref)
+    k = slope_class(torch.tensor([[10., 0], [30, 5]], dtype=torch.float64, device=dev),
+                    torch.tensor([[11, 20], [25, 5.2]], device=dev))
+    assert k.tolist() == [[1, 255], [-1, 1]]
+
+
+# ================================================================================ AdamW
+def test_fused_adamw_matches_torch(dev):
+    from gedepth_amd.mmrt.optim import FusedAdamW
+    torch.manual_seed(0)
+    shapes = [(33, 7), (129,), (5, 3, 3, 3), (1,)]
+    ref_params = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    our_params = [p.detach().clone().requires_grad_(True) for p in ref_params]
+    ref = torch.optim.AdamW([dict(params=ref_params[:2], weight_decay=0.01), dict(params=ref_params[2:], weight_decay=0.0)],
+                            lr=1e-3, betas=(0.9, 0.999))
+    ours = FusedAdamW([dict(params=our_params[:2], weight_decay=0.01), dict(params=our_params[2:], weight_decay=0.0)],
+                      lr=1e-3, betas=(0.9, 0.999), max_grad_norm=0.5)
+    for step in range(5):
+        grads = [torch.randn(s, device=dev) for s in shapes]
+        for p, q, g in zip(ref_params, our_params, grads):
+            p.grad = g.clone()
+            q.grad.copy_(g)                 # .grad is a view into the flat gradient arena
+        torch.nn.utils.clip_grad_norm_(ref_params, 0.5)
+        ref.step()
+        ours.step()
+        for p, q in zip(ref_params, our_params):
+            close(q, p, rtol=1e-5, atol=1e-7, what=f'step {step}')
