@@ -3,11 +3,11 @@
 //   depth fusion, offline ground-plane / slope-class maps, SiLog statistics, fused AdamW.
 // None of these is a contraction, so no MFMA: one pixel (or one 16-byte vector) per lane, coalesced
 // along W, low-resolution operands served from L1/L2.  See DESIGN.md for bytes/pixel per kernel.
-#include "common.h"
-
-// keep mul/add un-fused so that resize weights / the validity mask follow the same IEEE operation sequence as
-// the reference's ATen kernels
+// Keep mul/add un-fused everywhere in this translation unit (including inlined header helpers) so that resize
+// weights, the validity mask and the fp64 ground-plane map follow the same IEEE operation sequence as the
+// reference's ATen / numpy code.  Must precede every include: contraction flags are attached per operation.
 #pragma clang fp contract(off)
+#include "common.h"
 
 // ====================================================================================== bilinear
 template <typename T>
@@ -353,10 +353,10 @@ __global__ void __launch_bounds__(256) ground_plane_k(double r0, double r1, doub
   const long total = (long)H * W;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     int v = (int)(idx / W), u = (int)(idx - (long)v * W);
-    // numpy evaluates (r0*u + r1*v) + r2 with separately rounded products: keep fp contraction off
-    double t0 = __dmul_rn(r0, (double)u), t1 = __dmul_rn(r1, (double)v);
-    double den = __dadd_rn(__dadd_rn(t0, t1), r2);
-    double pe = num / den;
+    // numpy evaluates (r0*u + r1*v) + r2 with separately rounded products (contraction is off in this file)
+    const double t0 = r0 * (double)u, t1 = r1 * (double)v;
+    const double den = (t0 + t1) + r2;
+    const double pe = num / den;
     if (pe64) pe64[idx] = pe;
     if (pe32) pe32[idx] = (float)pe;
   }

@@ -1,6 +1,440 @@
-// bf16 MFMA tile variant of the window-attention core (placeholder until implemented).
+// Swin shifted-window attention core for gfx950 — bf16 MFMA tile variant (the performance path).
+//
+// One wave64 per (batch, window, head).  The 49 x 32 q / k / v rows of the 7x7 window are staged in LDS
+// (16-byte pieces; pad tokens take the qkv bias; rows 49..63 are zero) and every contraction runs on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//
+//   forward   S^T = K Q^T   (64 keys x 64 queries as 2x2 tiles, K=32)   8 MFMA
+//             O^T = V^T P^T (32 dims x 64 queries,                K=64) 8 MFMA
+//   backward  S^T, dP^T = V dO^T (8+8), dQ^T = K^T dS^T (8), dV^T = dO^T P (8), dK^T = Q^T dS (8)
+//
+// S is computed TRANSPOSED so that, in the MFMA C/D layout (col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)),
+// a lane owns one query column: soft-max statistics are lane-local plus one lane^32 exchange, and the P / dS
+// accumulators are already in B-operand layout for the products contracted over keys.  The key order inside
+// a K=16 step is permuted (kappa(s,hi,e) = 16 s + 4 hi + (e&3) + 8 (e>>2)) to match that register order — a
+// contraction is invariant to a common permutation of A's and B's k-slots, so no cross-lane shuffles are needed.
+// Products contracted over QUERIES (dV, dK) need P / dS with lane <-> key: those 64 x 32 half-tiles are transposed
+// through LDS (bf16), two query tiles one after the other, reusing V's staging buffer.
+//
+// HBM traffic is the algorithmic minimum: q,k,v (+dO) read once, out (dqkv) written once; the op is HBM-bound
+// (24.5 FLOP/B at bf16, ridge 312 FLOP/B) and MFMA only has to keep the arithmetic off the critical path.
 #include "common.h"
 #include "window_attn.h"
-extern const int ge_window_attn_mfma_available = 0;
-int ge_window_attn_fwd_mfma(const void*, const float*, const float*, void*, const WinGeom&, float, hipStream_t) { return GE_ERR_UNSUPPORTED; }
-int ge_window_attn_bwd_mfma(const void*, const float*, const float*, const void*, void*, float*, const WinGeom&, float, int, hipStream_t) { return GE_ERR_UNSUPPORTED; }
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RLD 40   // row-major bf16 tiles: 64 rows x (32 + 8 pad) -> 80-byte rows: ds_read_b128 conflict-free
+#define VLD 68   // transposed V tile: 32 dims x (64 + 4 pad) keys -> 136-byte rows (8-byte aligned)
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // -> v_cvt_pk_bf16_f32 (round-to-nearest-even)
+  bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ bf16_t f2bf_hw(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {   // v[base .. base+7] -> 8 bf16
+  uint4 u;
+  u.x = pack2(v[base + 0], v[base + 1]); u.y = pack2(v[base + 2], v[base + 3]);
+  u.z = pack2(v[base + 4], v[base + 5]); u.w = pack2(v[base + 6], v[base + 7]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+// register r of the C/D layout -> row inside the 32-row tile
+__device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// 8 bf16 of one column `col` of a row-major [.][RLD] tile, rows kappa(base, e), e = 0..7  (A operand of X^T products)
+__device__ __forceinline__ bf16x8 col8(const bf16_t* tile, int base_row, int col) {
+  uint32_t w[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int e0 = 2 * p, e1 = 2 * p + 1;
+    const int r0 = base_row + (e0 & 3) + 8 * (e0 >> 2), r1 = base_row + (e1 & 3) + 8 * (e1 >> 2);
+    w[p] = (uint32_t)tile[r0 * RLD + col] | ((uint32_t)tile[r1 * RLD + col] << 16);
+  }
+  uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+// same but rows are CONSECUTIVE (base_row + e): used for the query-contracted products
+__device__ __forceinline__ bf16x8 col8_lin(const bf16_t* tile, int base_row, int col) {
+  uint32_t w[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    w[p] = (uint32_t)tile[(base_row + 2 * p) * RLD + col] | ((uint32_t)tile[(base_row + 2 * p + 1) * RLD + col] << 16);
+  uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ bf16x8 row8(const bf16_t* tile, int row, int col0) {   // 16-byte aligned row fragment
+  return __builtin_bit_cast(bf16x8, *(const uint4*)(tile + row * RLD + col0));
+}
+
+// Stage a 49 x 32 bf16 operand row-major into LDS (rows >= 49 zero).  pad rows take `padval` (fp32 -> bf16).
+__device__ __forceinline__ void stage_rm(const bf16_t* __restrict__ base, long row_stride, int col0, const int* tok,
+                                         const float* __restrict__ padval, bf16_t* dst, int lane) {
+  uint4 v[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = lane + it * 64;           // 64 rows x 4 pieces of 8 bf16
+    const int t = piece >> 2, part = (piece & 3) * 8;
+    v[it] = make_uint4(0, 0, 0, 0);
+    if (t < WT) {
+      const int src = tok[t];
+      if (src >= 0) {
+        v[it] = *(const uint4*)(base + (long)src * row_stride + col0 + part);
+      } else if (padval) {
+        const float* pv = padval + col0 + part;
+        v[it] = make_uint4(pack2(pv[0], pv[1]), pack2(pv[2], pv[3]), pack2(pv[4], pv[5]), pack2(pv[6], pv[7]));
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = lane + it * 64;
+    const int t = piece >> 2, part = (piece & 3) * 8;
+    *(uint4*)(dst + t * RLD + part) = v[it];
+  }
+}
+// Stage V transposed: vt[d][key], keys >= 49 zero.
+__device__ __forceinline__ void stage_vt(const bf16_t* __restrict__ base, long row_stride, int col0, const int* tok,
+                                         const float* __restrict__ padval, bf16_t* vt, int lane) {
+  uint4 v[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = lane + it * 64;
+    const int t = piece >> 2, part = (piece & 3) * 8;
+    v[it] = make_uint4(0, 0, 0, 0);
+    if (t < WT) {
+      const int src = tok[t];
+      if (src >= 0) {
+        v[it] = *(const uint4*)(base + (long)src * row_stride + col0 + part);
+      } else {
+        const float* pv = padval + col0 + part;
+        v[it] = make_uint4(pack2(pv[0], pv[1]), pack2(pv[2], pv[3]), pack2(pv[4], pv[5]), pack2(pv[6], pv[7]));
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = lane + it * 64;
+    const int t = piece >> 2, part = (piece & 3) * 8;
+    const uint32_t w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt[(part + e) * VLD + t] = (bf16_t)((w[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+  }
+}
+
+struct WinMeta {            // per-window token tables in LDS
+  int tok[64];
+  uint32_t meta[64];        // kb | region << 16, kb = i*13 + j
+};
+__device__ __forceinline__ void fill_meta(const WinGeom& g, int wy, int wx, int lane, WinMeta& m) {
+  int tk = -1, region = 0, kb = 0;
+  if (lane < WT) {
+    tk = win_token(g, wy, wx, lane, region);
+    const int i = lane / WS, j = lane - i * WS;
+    kb = i * 13 + j;
+  }
+  m.tok[lane] = tk;
+  m.meta[lane] = (uint32_t)kb | ((uint32_t)region << 16);
+}
+
+// S^T tiles: acc[kt][qt] (row = key, col = query) from row-major K and Q tiles
+__device__ __forceinline__ void st_tiles(const bf16_t* A_rows, const bf16_t* B_rows, int c, int hi, f32x16 acc[2][2]) {
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kt][qt][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8 a0 = row8(A_rows, c, ks * 16 + hi * 8), a1 = row8(A_rows, 32 + c, ks * 16 + hi * 8);
+    const bf16x8 b0 = row8(B_rows, c, ks * 16 + hi * 8), b1 = row8(B_rows, 32 + c, ks * 16 + hi * 8);
+    acc[0][0] = mfma_bf16(a0, b0, acc[0][0]);
+    acc[0][1] = mfma_bf16(a0, b1, acc[0][1]);
+    acc[1][0] = mfma_bf16(a1, b0, acc[1][0]);
+    acc[1][1] = mfma_bf16(a1, b1, acc[1][1]);
+  }
+}
+
+// scores -> normalised probabilities, in place.  Lane owns query columns c (qt=0) and 32+c (qt=1).
+__device__ __forceinline__ void softmax_cols(f32x16 acc[2][2], const float* bias, const uint32_t* meta, int c, int hi,
+                                             float scale, bool use_mask) {
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + c;
+    const uint32_t mq = meta[q < WT ? q : 0];
+    const int qb = (int)(mq & 0xffffu) + 6 * 13 + 6;      // (iq+6)*13 + jq + 6
+    const int rq = (int)(mq >> 16);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + crow(r, hi);
+        float s = -INFINITY;
+        if (key < WT) {
+          const uint32_t mk = meta[key];
+          s = acc[kt][qt][r] * scale + bias[qb - (int)(mk & 0xffffu)];
+          if (use_mask && (int)(mk >> 16) != rq) s += -100.0f;
+        }
+        acc[kt][qt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(acc[kt][qt][r] - mx);
+        acc[kt][qt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= inv;
+  }
+}
+
+// store a (32 dims x 32 cols) C/D tile as rows of `dst`: column `col_tok` (token index) gets dims d = crow(r,hi)
+__device__ __forceinline__ void store_cols(const f32x16& o, float mul, bf16_t* __restrict__ row_ptr, int hi) {
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    uint2 u;
+    u.x = pack2(o[4 * gq + 0] * mul, o[4 * gq + 1] * mul);
+    u.y = pack2(o[4 * gq + 2] * mul, o[4 * gq + 3] * mul);
+    *(uint2*)(row_ptr + 8 * gq + 4 * hi) = u;
+  }
+}
+
+// ============================================================================================ forward
+struct WinSmemMfmaFwd {
+  bf16_t k[64 * RLD];
+  bf16_t q[64 * RLD];
+  bf16_t vt[HD * VLD];
+  float bias[NBIAS + 7];
+  WinMeta m;
+};
+
+__global__ void __launch_bounds__(64) window_attn_fwd_mfma_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                             const float* __restrict__ bias_table, bf16_t* __restrict__ out,
+                                                             WinGeom g, float scale) {
+  __shared__ __attribute__((aligned(16))) WinSmemMfmaFwd sm;
+  const int lane = threadIdx.x, c = lane & 31, hi = lane >> 5;
+  const int item = blockIdx.x;
+  const int head = item % g.nH;
+  const int bw = item / g.nH;
+  const int nW = g.nWh * g.nWw;
+  const int b = bw / nW, win = bw - b * nW;
+  const int wy = win / g.nWw, wx = win - wy * g.nWw;
+  fill_meta(g, wy, wx, lane, sm.m);
+  for (int i = lane; i < NBIAS; i += GE_WAVE) sm.bias[i] = bias_table[i * g.nH + head];
+  __syncthreads();
+  const long L = (long)g.H * g.W;
+  const bf16_t* base = qkv + (long)b * L * 3 * g.C;
+  stage_rm(base, 3 * g.C, head * HD, sm.m.tok, qkv_bias, sm.q, lane);
+  stage_rm(base, 3 * g.C, g.C + head * HD, sm.m.tok, qkv_bias, sm.k, lane);
+  stage_vt(base, 3 * g.C, 2 * g.C + head * HD, sm.m.tok, qkv_bias, sm.vt, lane);
+  __syncthreads();
+
+  f32x16 acc[2][2];
+  st_tiles(sm.k, sm.q, c, hi, acc);
+  const bool use_mask = g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+  softmax_cols(acc, sm.bias, sm.m.meta, c, hi, scale, use_mask);
+
+  // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]; k-slot (hi,e) <-> key kappa = kt*32 + 16 s + 4 hi + (e&3) + 8 (e>>2)
+  f32x16 o[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[qt][i] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kb = kt * 32 + 16 * s + 4 * hi;
+      const uint2 lo = *(const uint2*)(sm.vt + c * VLD + kb), hi8 = *(const uint2*)(sm.vt + c * VLD + kb + 8);
+      const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi8.x, hi8.y));
+      o[0] = mfma_bf16(a, pack8(acc[kt][0], 8 * s), o[0]);
+      o[1] = mfma_bf16(a, pack8(acc[kt][1], 8 * s), o[1]);
+    }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + c;
+    if (q < WT) {
+      const int dst = sm.m.tok[q];
+      if (dst >= 0) store_cols(o[qt], 1.f, out + ((long)b * L + dst) * g.C + head * HD, hi);
+    }
+  }
+}
+
+// =========================================================================================== backward
+struct WinSmemMfmaBwd {
+  bf16_t k[64 * RLD];
+  bf16_t q[64 * RLD];
+  bf16_t v[64 * RLD];       // re-used as the [key][32 queries] transpose buffer after dP is formed
+  bf16_t go[64 * RLD];
+  float bias[NBIAS + 7];
+  float dbias[NBIAS + 7];
+  float dpad[2 * HD];
+  WinMeta m;
+};
+#define WS_PER_WG_MFMA (NBIAS + 2 * HD)
+
+__global__ void __launch_bounds__(64) window_attn_bwd_mfma_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                             const float* __restrict__ bias_table, const bf16_t* __restrict__ gout,
+                                                             bf16_t* __restrict__ dqkv, float* __restrict__ workspace,
+                                                             WinGeom g, float scale, int wg_per_head) {
+  __shared__ __attribute__((aligned(16))) WinSmemMfmaBwd sm;
+  const int lane = threadIdx.x, c = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.x % g.nH;
+  const int slot = blockIdx.x / g.nH;
+  const int nW = g.nWh * g.nWw;
+  const int n_bw = g.B * nW;
+  const long L = (long)g.H * g.W;
+  for (int i = lane; i < NBIAS; i += GE_WAVE) { sm.bias[i] = bias_table[i * g.nH + head]; sm.dbias[i] = 0.f; }
+  sm.dpad[lane] = 0.f;
+  __syncthreads();
+
+  for (int bw = slot; bw < n_bw; bw += wg_per_head) {
+    const int b = bw / nW, win = bw - b * nW;
+    const int wy = win / g.nWw, wx = win - wy * g.nWw;
+    fill_meta(g, wy, wx, lane, sm.m);
+    __syncthreads();
+    const bf16_t* base = qkv + (long)b * L * 3 * g.C;
+    stage_rm(base, 3 * g.C, head * HD, sm.m.tok, qkv_bias, sm.q, lane);
+    stage_rm(base, 3 * g.C, g.C + head * HD, sm.m.tok, qkv_bias, sm.k, lane);
+    stage_rm(base, 3 * g.C, 2 * g.C + head * HD, sm.m.tok, qkv_bias, sm.v, lane);
+    stage_rm(gout + (long)b * L * g.C, g.C, head * HD, sm.m.tok, nullptr, sm.go, lane);
+    __syncthreads();
+
+    f32x16 P[2][2], dS[2][2];
+    st_tiles(sm.k, sm.q, c, hi, P);
+    const bool use_mask = g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+    softmax_cols(P, sm.bias, sm.m.meta, c, hi, scale, use_mask);
+    st_tiles(sm.v, sm.go, c, hi, dS);                       // dP^T = V dO^T
+    __syncthreads();                                        // all lanes done reading sm.v -> transpose buffer
+
+    // dS = P (dP - delta), delta = sum_key P dP per query;  bias-table gradient
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float delta = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta += P[kt][qt][r] * dS[kt][qt][r];
+      delta += __shfl_xor(delta, 32, 64);
+      const int q = qt * 32 + c;
+      const int qb = (int)(sm.m.meta[q < WT ? q : 0] & 0xffffu) + 6 * 13 + 6;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ds = P[kt][qt][r] * (dS[kt][qt][r] - delta);
+          dS[kt][qt][r] = ds;
+          const int key = kt * 32 + crow(r, hi);
+          if (q < WT && key < WT) atomicAdd(&sm.dbias[qb - (int)(sm.m.meta[key] & 0xffffu)], ds);
+        }
+    }
+
+    // dQ^T[d][query] = scale * sum_key K^T[d][key] dS^T[key][query]
+    {
+      f32x16 dq[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[qt][i] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 a = col8(sm.k, kt * 32 + 16 * s + 4 * hi, c);
+          dq[0] = mfma_bf16(a, pack8(dS[kt][0], 8 * s), dq[0]);
+          dq[1] = mfma_bf16(a, pack8(dS[kt][1], 8 * s), dq[1]);
+        }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int q = qt * 32 + c;
+        if (q < WT) {
+          const int dst = sm.m.tok[q];
+          if (dst >= 0) store_cols(dq[qt], scale, dqkv + ((long)b * L + dst) * 3 * g.C + head * HD, hi);
+        }
+      }
+    }
+
+    // dV^T[d][key] = sum_q dO^T[d][q] P[q][key];  dK^T[d][key] = scale * sum_q Q^T[d][q] dS[q][key]
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dv[kt][i] = 0.f; dk[kt][i] = 0.f; }
+    bf16_t* tb = sm.v;                                       // [64 keys][RLD], columns 0..31 = queries of tile qt
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {                 // pass 0: P -> dV ; pass 1: dS -> dK
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tb[(kt * 32 + crow(r, hi)) * RLD + c] = f2bf_hw(pass == 0 ? P[kt][qt][r] : dS[kt][qt][r]);
+        __syncthreads();
+        const bf16_t* lhs = pass == 0 ? sm.go : sm.q;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 a = col8_lin(lhs, qt * 32 + ks * 16 + hi * 8, c);    // X^T[d = c][8 consecutive queries]
+          const bf16x8 b0 = row8(tb, c, ks * 16 + hi * 8), b1 = row8(tb, 32 + c, ks * 16 + hi * 8);
+          if (pass == 0) { dv[0] = mfma_bf16(a, b0, dv[0]); dv[1] = mfma_bf16(a, b1, dv[1]); }
+          else { dk[0] = mfma_bf16(a, b0, dk[0]); dk[1] = mfma_bf16(a, b1, dk[1]); }
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int key = kt * 32 + c;
+      if (key < WT) {
+        const int dst = sm.m.tok[key];
+        if (dst >= 0) {
+          bf16_t* rp = dqkv + ((long)b * L + dst) * 3 * g.C + head * HD;
+          store_cols(dk[kt], scale, rp + g.C, hi);
+          store_cols(dv[kt], 1.f, rp + 2 * g.C, hi);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            atomicAdd(&sm.dpad[crow(r, hi)], dk[kt][r] * scale);
+            atomicAdd(&sm.dpad[HD + crow(r, hi)], dv[kt][r]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* wsp = workspace + (long)blockIdx.x * WS_PER_WG_MFMA;
+  for (int i = lane; i < NBIAS; i += GE_WAVE) wsp[i] = sm.dbias[i];
+  wsp[NBIAS + lane] = sm.dpad[lane];
+}
+
+extern const int ge_window_attn_mfma_available = 3;   // bit0: forward, bit1: backward
+
+int ge_window_attn_fwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, void* out, const WinGeom& g,
+                            float scale, hipStream_t s) {
+  const long items = (long)g.B * g.nWh * g.nWw * g.nH;
+  window_attn_fwd_mfma_k<<<(unsigned)items, 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table, (bf16_t*)out, g, scale);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+int ge_window_attn_bwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, const void* d_out, void* d_qkv,
+                            float* workspace, const WinGeom& g, float scale, int wg_per_head, hipStream_t s) {
+  window_attn_bwd_mfma_k<<<(unsigned)(wg_per_head * g.nH), 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table,
+                                                                       (const bf16_t*)d_out, (bf16_t*)d_qkv, workspace, g,
+                                                                       scale, wg_per_head);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}

@@ -1,0 +1,45 @@
+"""Batching for dict samples (mmcv ``collate`` semantics for this path: tensors stacked, ``img_metas`` kept as a
+list) and a DistributedSampler-backed loader (depth/datasets/builder.py:93-149)."""
+import torch
+from torch.utils.data import DataLoader, DistributedSampler
+
+from ...mmrt.runner import get_dist_info
+
+
+def collate(samples):
+    out = {}
+    for k in samples[0]:
+        vals = [s[k] for s in samples]
+        if k == 'img_metas':
+            out[k] = vals
+        elif torch.is_tensor(vals[0]):
+            out[k] = torch.stack(vals, 0)
+        else:
+            out[k] = torch.as_tensor(vals)
+    return out
+
+
+def build_dataloader(dataset, samples_per_gpu, workers_per_gpu=0, dist=True, shuffle=True, seed=None, drop_last=False,
+                     pin_memory=True, **kwargs):
+    rank, world = get_dist_info()
+    sampler = DistributedSampler(dataset, world, rank, shuffle=shuffle, seed=seed or 0) if dist else None
+    return DataLoader(dataset, batch_size=samples_per_gpu, sampler=sampler, shuffle=(shuffle and sampler is None),
+                      num_workers=workers_per_gpu, collate_fn=collate, pin_memory=pin_memory, drop_last=drop_last)
+
+
+class SyntheticKITTI(torch.utils.data.Dataset):
+    """Fixed-size synthetic KITTI-shaped dataset (one seeded sample per index)."""
+
+    def __init__(self, length=64, height=352, width=1120, adaptive=True, seed=1234):
+        self.length, self.h, self.w, self.adaptive, self.seed = length, height, width, adaptive, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        from .synthetic import synthetic_batch
+        b = synthetic_batch(1, self.h, self.w, seed=self.seed + i)
+        out = dict(img=b['img'][0], img_metas=b['img_metas'][0], depth_gt=b['depth_gt'][0])
+        if self.adaptive:
+            out['pe_k_gt'] = b['pe_k_gt'][0]
+        return out

@@ -1,0 +1,186 @@
+"""Multi-process data-parallel path on CPU (gloo, world_size 2): flat-arena bucketed all-reduce, parameter
+broadcast, fused scalar all-reduce of the log vars, and the iteration-based runner.  SURVEY.md §8(e)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gedepth_amd.depth.models.depther.base import BaseDepther, DeferredLogVars  # noqa: E402
+from gedepth_amd.mmrt.ddp import FlatDDP  # noqa: E402
+from gedepth_amd.mmrt.optim import CosineAnnealingLr, GradArena, paramwise_groups  # noqa: E402
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 32)
+        self.norm = nn.LayerNorm(32)
+        self.b = nn.Linear(32, 16)
+        self.c = nn.Linear(16, 1)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(self.norm(torch.relu(self.a(x))))))
+
+    def train_step(self, batch, optimizer=None):
+        loss = (self(batch['x']) - batch['y']).pow(2).mean()
+        l, lv = BaseDepther._parse_losses({'loss_mse': loss, 'aux': loss.detach() * 2})
+        return dict(loss=l, log_vars=lv, num_samples=len(batch['x']))
+
+
+class ArenaSGD:
+    """Minimal optimizer over a GradArena for the CPU tests (the product's FusedAdamW is MI355X-only)."""
+
+    def __init__(self, model, lr=0.1):
+        self.arena = GradArena(model.parameters())
+        self.defaults = dict(lr=lr)
+        self.param_groups = [dict(lr=lr, params=self.arena.params)]
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+
+    def step(self):
+        self.arena.flat_param.add_(self.arena.flat_grad, alpha=-self.param_groups[0]['lr'])
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, state):
+        pass
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
+    model = Toy()
+    opt = ArenaSGD(model)
+    ddp = FlatDDP(model, opt.arena, bucket_mb=0.0005)  # ~130 floats per bucket -> several buckets
+    assert len(ddp.buckets) >= 3
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(8, 8, generator=g), torch.randn(8, 1, generator=g)
+    batch = dict(x=X[rank * 4:(rank + 1) * 4], y=Y[rank * 4:(rank + 1) * 4])
+    opt.zero_grad()
+    out = ddp.train_step(batch)
+    out['loss'].backward()
+    ddp.finish()
+    res = dict(params={k: v.clone() for k, v in model.state_dict().items()},
+               grad=opt.arena.flat_grad.clone(), log=dict(out['log_vars']), local_loss=out['loss'].item())
+    # second iteration exercises the bucket state reset
+    opt.step()
+    opt.zero_grad()
+    out = ddp.train_step(batch)
+    out['loss'].backward()
+    ddp.finish()
+    res['grad2'] = opt.arena.flat_grad.clone()
+    torch.save(res, os.path.join(tmp, f'r{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_gloo_world2(tmp_path):
+    port = free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'r{i}.pt', weights_only=False) for i in range(2))
+    # broadcast: both ranks hold rank 0's initial parameters
+    for k in r0['params']:
+        assert torch.equal(r0['params'][k], r1['params'][k]), k
+    # gradients: identical across ranks and equal to the full-batch gradient of a single process
+    assert torch.equal(r0['grad'], r1['grad'])
+    assert torch.equal(r0['grad2'], r1['grad2'])
+    torch.manual_seed(100)
+    ref = Toy()
+    ref.load_state_dict(r0['params'])
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(8, 8, generator=g), torch.randn(8, 1, generator=g)
+    arena = GradArena(ref.parameters())
+    (ref(X) - Y).pow(2).mean().backward()
+    assert torch.allclose(arena.flat_grad, r0['grad'], rtol=1e-5, atol=1e-7)
+    # log vars: mean over ranks, one fused all-reduce
+    assert abs(r0['log']['loss'] - 0.5 * (r0['local_loss'] + r1['local_loss'])) < 1e-6
+    assert abs(r0['log']['aux'] - 2 * r0['log']['loss_mse']) < 1e-6
+    assert r0['log'] == r1['log']
+
+
+def test_deferred_log_vars_single_process():
+    lv = DeferredLogVars(['a', 'b'], torch.tensor([1.5, 2.5]))
+    assert lv.tensor() is not None
+    assert lv['a'] == 1.5 and dict(lv.items()) == {'a': 1.5, 'b': 2.5} and lv.tensor() is None
+    loss, lv = BaseDepther._parse_losses({'loss_x': torch.tensor([1.0, 3.0]), 'acc': torch.tensor(0.5),
+                                          'loss_list': [torch.tensor(1.0), torch.tensor(2.0)]})
+    assert loss.item() == 5.0 and lv['loss'] == 5.0 and lv['loss_x'] == 2.0 and lv['acc'] == 0.5
+    with pytest.raises(TypeError):
+        BaseDepther._parse_losses({'loss': 1.0})
+
+
+def test_cosine_lr_with_linear_warmup():
+    """mmcv CosineAnnealing by iteration + linear warm-up (configs/depthformer/depthformer_v.py:141-147)."""
+    s = CosineAnnealingLr(1e-4, 76800, min_lr_ratio=1e-8, warmup='linear', warmup_iters=25600, warmup_ratio=1e-3)
+    assert abs(s.lr_at(0) - 1e-4 * 1e-3) < 1e-12
+    import math
+    reg = lambda it: 1e-12 + 0.5 * (1e-4 - 1e-12) * (math.cos(math.pi * it / 76800) + 1)
+    it = 12800
+    assert abs(s.lr_at(it) - reg(it) * (1 - (1 - it / 25600) * (1 - 1e-3))) < 1e-15
+    assert abs(s.lr_at(25600) - reg(25600)) < 1e-15
+    assert abs(s.lr_at(76800) - 1e-12) < 1e-15
+
+
+def test_paramwise_decay_mult():
+    from gedepth_amd.depth.models import build_depther
+    from gedepth_amd.mmrt.config import Config
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    cfg.model.pretrained = None
+    cfg.model.backbone.depths = [1, 1, 1, 1]
+    m = build_depther(cfg.model)
+    groups = {g['name']: g for g in paramwise_groups(m, 1e-4, 0.01, cfg.optimizer.paramwise_cfg)}
+    assert groups['backbone.stages.0.blocks.0.attn.w_msa.relative_position_bias_table']['weight_decay'] == 0
+    assert groups['backbone.stages.0.blocks.0.norm1.weight']['weight_decay'] == 0
+    assert groups['backbone.norm2.bias']['weight_decay'] == 0
+    assert groups['backbone.stages.0.downsample.norm.weight']['weight_decay'] == 0
+    assert groups['backbone.stages.0.blocks.0.attn.w_msa.qkv.weight']['weight_decay'] == 0.01
+    assert groups['neck.lateral_convs.0.bn.weight']['weight_decay'] == 0.01     # 'norm' is not a substring of 'bn'
+    assert groups['decode_head.conv_depth.weight']['weight_decay'] == 0.01
+
+
+def test_runner_hooks_checkpoint_resume(tmp_path):
+    from gedepth_amd.mmrt.runner import IterBasedRunner
+    torch.manual_seed(0)
+    model = Toy()
+    opt = ArenaSGD(model, lr=0.05)
+    logs = []
+    runner = IterBasedRunner(model, opt, work_dir=str(tmp_path), logger=logs.append, max_iters=12)
+    runner.register_training_hooks(dict(policy='CosineAnnealing', warmup='linear', warmup_iters=4, warmup_ratio=0.1,
+                                        min_lr_ratio=1e-3, by_epoch=False),
+                                   dict(grad_clip=None), dict(by_epoch=False, interval=4, max_keep_ckpts=2),
+                                   dict(interval=3, hooks=[dict(type='TextLoggerHook', by_epoch=False),
+                                                           dict(type='TensorboardLoggerHook')]))
+    g = torch.Generator().manual_seed(0)
+    data = [dict(x=torch.randn(4, 8, generator=g), y=torch.randn(4, 1, generator=g)) for _ in range(3)]
+    runner.run([data])
+    assert runner.iter == 12 and len(logs) == 4
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith('.pth')) == ['iter_12.pth', 'iter_8.pth']
+    first, last = float(logs[0].split('loss: ')[1].split(',')[0]), float(logs[-1].split('loss: ')[1].split(',')[0])
+    assert last < first
+    ckpt = torch.load(tmp_path / 'iter_12.pth', weights_only=False)
+    assert set(ckpt) >= {'meta', 'state_dict'} and ckpt['meta']['iter'] == 12
+    model2 = Toy()
+    r2 = IterBasedRunner(model2, ArenaSGD(model2), work_dir=str(tmp_path), logger=logs.append, max_iters=12)
+    r2.resume(str(tmp_path / 'iter_12.pth'))
+    assert r2.iter == 12
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, model2.state_dict()[k])
