@@ -125,200 +125,388 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
     const float* ap = attw + grp * (long)LP;
     const long vbase = ((long)b * Nv * nH + head) * 64 + lane;
     const float go = Ld1<T>::ld(gout + grp * 64 + lane);
-    for (int c0 = 0; c0 < LP; c0 += 32) {                         // 32 points per chunk: 64 loc floats, 32 weights
-      const int npt = min(32, LP - c0);
-      const float locv = (lane < 2 * npt) ? lp[c0 * 2 + lane] : 0.f;
-      const float attv = (lane < npt) ? ap[c0 + lane] : 0.f;
-      float my_dattw = 0.f, my_dloc = 0.f;                        // results for point `lane` / loc float `lane`
-      for (int j = 0; j < npt; ++j) {
-        const int pt = c0 + j;
-        const int l = pt / P;
+    // per point: 4 taps (wave-uniform branch structure), partial sums over this lane's channel
+#define MSDA_POINT(j_, l_, Hl_, Wl_, sv_, sx_, sy_)                                                      \
+    {                                                                                                    \
+      const float lx = readlane_f(locv, 2 * (j_)), ly = readlane_f(locv, 2 * (j_) + 1);                  \
+      const float wgt = readlane_f(attv, (j_));                                                          \
+      const float x = lx * (float)(Wl_) - 0.5f, y = ly * (float)(Hl_) - 0.5f;                            \
+      float s_val = 0.f, s_dx = 0.f, s_dy = 0.f;                                                         \
+      if (y > -1.f && x > -1.f && y < (float)(Hl_) && x < (float)(Wl_)) {                                \
+        const float xf = floorf(x), yf = floorf(y);                                                      \
+        const int x0 = (int)xf, y0 = (int)yf;                                                            \
+        const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;                              \
+        const long lbase = vbase + (long)lv.start[(l_)] * nH * 64;                                       \
+        const float gw = go * wgt;                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                  \
+          const int xx = x0 + (t & 1), yy = y0 + (t >> 1);                                               \
+          if (yy >= 0 && yy < (Hl_) && xx >= 0 && xx < (Wl_)) {                                          \
+            const long o = lbase + ((long)yy * (Wl_) + xx) * nH * 64;                                    \
+            const float wx = (t & 1) ? ax : bx, wy = (t >> 1) ? ay : by;                                 \
+            const float gv = go * Ld1<T>::ld(value + o);                                                 \
+            s_val += wy * wx * gv;                                                                       \
+            s_dx += ((t & 1) ? wy : -wy) * gv;                                                           \
+            s_dy += ((t >> 1) ? wx : -wx) * gv;                                                          \
+            if (VALUE_ATOMICS) atomicAdd(d_value + o, gw * (wy * wx));                                   \
+          }                                                                                              \
+        }                                                                                                \
+      }                                                                                                  \
+      sv_ = s_val; sx_ = s_dx * (wgt * (float)(Wl_)); sy_ = s_dy * (wgt * (float)(Hl_));                 \
+    }
+    if (P == 8 && LP <= 32) {
+      // 8 points per level: 24 partial sums reduced with a reduce-scatter butterfly (30 shuffles instead of 144)
+      const float locv = (lane < 2 * LP) ? lp[lane] : 0.f;
+      const float attv = (lane < LP) ? ap[lane] : 0.f;
+      for (int l = 0; l < L; ++l) {
         const int Hl = lv.H[l], Wl = lv.W[l];
-        const float lx = readlane_f(locv, 2 * j), ly = readlane_f(locv, 2 * j + 1);
-        const float wgt = readlane_f(attv, j);
-        const float x = lx * (float)Wl - 0.5f, y = ly * (float)Hl - 0.5f;
-        float s_val = 0.f, s_dx = 0.f, s_dy = 0.f;
-        if (y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl) {          // wave-uniform branch
-          const float xf = floorf(x), yf = floorf(y);
-          const int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
-          const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;
-          const long lbase = vbase + (long)lv.start[l] * nH * 64;
-          const float gw = go * wgt;
-          if (y0 >= 0 && x0 >= 0) {
-            const long o = lbase + ((long)y0 * Wl + x0) * nH * 64;
-            const float gv = go * Ld1<T>::ld(value + o);
-            s_val += by * bx * gv; s_dx -= by * gv; s_dy -= bx * gv;
-            if (VALUE_ATOMICS) atomicAdd(d_value + o, gw * (by * bx));
-          }
-          if (y0 >= 0 && x1 < Wl) {
-            const long o = lbase + ((long)y0 * Wl + x1) * nH * 64;
-            const float gv = go * Ld1<T>::ld(value + o);
-            s_val += by * ax * gv; s_dx += by * gv; s_dy -= ax * gv;
-            if (VALUE_ATOMICS) atomicAdd(d_value + o, gw * (by * ax));
-          }
-          if (y1 < Hl && x0 >= 0) {
-            const long o = lbase + ((long)y1 * Wl + x0) * nH * 64;
-            const float gv = go * Ld1<T>::ld(value + o);
-            s_val += ay * bx * gv; s_dx -= ay * gv; s_dy += bx * gv;
-            if (VALUE_ATOMICS) atomicAdd(d_value + o, gw * (ay * bx));
-          }
-          if (y1 < Hl && x1 < Wl) {
-            const long o = lbase + ((long)y1 * Wl + x1) * nH * 64;
-            const float gv = go * Ld1<T>::ld(value + o);
-            s_val += ay * ax * gv; s_dx += ay * gv; s_dy += ax * gv;
-            if (VALUE_ATOMICS) atomicAdd(d_value + o, gw * (ay * ax));
+        float part[24];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) MSDA_POINT(l * 8 + p, l, Hl, Wl, part[p], part[8 + p], part[16 + p])
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          const bool up = lane & 32;
+          const float send = up ? part[k] : part[k + 12], keep = up ? part[k + 12] : part[k];
+          part[k] = keep + __shfl_xor(send, 32, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const bool up = lane & 16;
+          const float send = up ? part[k] : part[k + 6], keep = up ? part[k + 6] : part[k];
+          part[k] = keep + __shfl_xor(send, 16, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const bool up = lane & 8;
+          const float send = up ? part[k] : part[k + 3], keep = up ? part[k + 3] : part[k];
+          part[k] = keep + __shfl_xor(send, 8, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float v = part[k];
+          v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+          part[k] = v;
+        }
+        if ((lane & 7) == 0) {                             // lane bits 5,4,3 select which 3 of the 24 sums it holds
+          const int base = ((lane >> 5) & 1) * 12 + ((lane >> 4) & 1) * 6 + ((lane >> 3) & 1) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int idx = base + k;
+            const int which = idx >> 3, j = l * 8 + (idx & 7);
+            if (which == 0) d_attw[grp * (long)LP + j] = part[k];
+            else d_loc[(grp * (long)LP + j) * 2 + (which - 1)] = part[k];
           }
         }
-        s_val = wave_sum(s_val);
-        s_dx = wave_sum(s_dx) * wgt * (float)Wl;
-        s_dy = wave_sum(s_dy) * wgt * (float)Hl;
-        if (lane == j) my_dattw = s_val;
-        if (lane == 2 * j) my_dloc = s_dx;
-        if (lane == 2 * j + 1) my_dloc = s_dy;
       }
-      if (lane < npt) d_attw[grp * (long)LP + c0 + lane] = my_dattw;           // coalesced result rows
-      if (lane < 2 * npt) d_loc[grp * (long)(LP * 2) + c0 * 2 + lane] = my_dloc;
+    } else {
+      for (int c0 = 0; c0 < LP; c0 += 32) {                       // generic: 32 points per chunk, plain wave sums
+        const int npt = min(32, LP - c0);
+        const float locv = (lane < 2 * npt) ? lp[c0 * 2 + lane] : 0.f;
+        const float attv = (lane < npt) ? ap[c0 + lane] : 0.f;
+        float my_dattw = 0.f, my_dloc = 0.f;
+        for (int j = 0; j < npt; ++j) {
+          const int l = (c0 + j) / P;
+          const int Hl = lv.H[l], Wl = lv.W[l];
+          float sv, sx, sy;
+          MSDA_POINT(j, l, Hl, Wl, sv, sx, sy)
+          sv = wave_sum(sv); sx = wave_sum(sx); sy = wave_sum(sy);
+          if (lane == j) my_dattw = sv;
+          if (lane == 2 * j) my_dloc = sx;
+          if (lane == 2 * j + 1) my_dloc = sy;
+        }
+        if (lane < npt) d_attw[grp * (long)LP + c0 + lane] = my_dattw;
+        if (lane < 2 * npt) d_loc[grp * (long)(LP * 2) + c0 * 2 + lane] = my_dloc;
+      }
+    }
+#undef MSDA_POINT
+  }
+}
+
+// d_loc / d_attw only (the binned path computes d_value separately): same 16-lane-group decomposition as the forward
+// kernel (4 channels per lane, one 16-byte / 8-byte load per tap and lane, four (query, head) pairs per wave), the three
+// per-point sums reduced over the group with a 4-step butterfly.
+template <typename T>
+__global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
+                                                     const float* __restrict__ attw, const T* __restrict__ gout,
+                                                     float* __restrict__ d_loc, float* __restrict__ d_attw, long n_groups,
+                                                     int Nv, int Nq, int nH, int L, int P) {
+  const int sub = threadIdx.x & 15;
+  const int c4 = sub * 4;
+  const long grp0 = (long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
+  const long gstride = (long)gridDim.x * (blockDim.x >> 4);
+  const long iters = (n_groups + gstride - 1) / gstride;          // wave-uniform trip count: the shuffles need all lanes
+  const int LP = L * P;
+  for (long it = 0; it < iters; ++it) {
+    const long grp = grp0 + it * gstride;
+    const bool live = grp < n_groups;
+    const long g_ = live ? grp : 0;
+    const int head = (int)(g_ % nH);
+    const int b = (int)((g_ / nH) / Nq);
+    const float* lp = loc + g_ * (long)(LP * 2);
+    const float* ap = attw + g_ * (long)LP;
+    const T* vb = value + ((long)b * Nv * nH + head) * 64 + c4;
+    float go[4];
+    Vec4<T>::ld(gout + g_ * 64 + c4, go);
+    for (int l = 0; l < L; ++l) {
+      const int Hl = lv.H[l], Wl = lv.W[l];
+      const T* vl = vb + (long)lv.start[l] * nH * 64;
+      for (int p = 0; p < P; ++p) {
+        const int j = l * P + p;
+        const float2 xy = *(const float2*)(lp + 2 * j);
+        const float wgt = ap[j];
+        const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;
+        float s_val = 0.f, s_dx = 0.f, s_dy = 0.f;
+        if (live && y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl) {
+          const float xf = floorf(x), yf = floorf(y);
+          const int x0 = (int)xf, y0 = (int)yf;
+          const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+            if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {
+              float v[4];
+              Vec4<T>::ld(vl + ((long)yy * Wl + xx) * nH * 64, v);
+              const float gv = go[0] * v[0] + go[1] * v[1] + go[2] * v[2] + go[3] * v[3];
+              const float wx = (t & 1) ? ax : bx, wy = (t >> 1) ? ay : by;
+              s_val += wy * wx * gv;
+              s_dx += ((t & 1) ? wy : -wy) * gv;
+              s_dy += ((t >> 1) ? wx : -wx) * gv;
+            }
+          }
+        }
+        s_val = group16_sum(s_val);
+        s_dx = group16_sum(s_dx);
+        s_dy = group16_sum(s_dy);
+        if (live && sub == 0) {
+          d_attw[g_ * (long)LP + j] = s_val;
+          *(float2*)(d_loc + (g_ * (long)LP + j) * 2) = make_float2(s_dx * wgt * (float)Wl, s_dy * wgt * (float)Hl);
+        }
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// d_value without per-tap atomics: "tile owner" scatter into REGISTERS.
-// Measured on MI355X (scratch/ubench): the L2 executes fp32 atomics at ~1 dword/clock/channel (5.0 G 256-byte
-// bursts/s chip-wide, independent of footprint and scope) and LDS fp32 atomics are slower still (ds_add_f32: ~170
-// cycles per wave-instruction per CU), which pinned the plain scatter at ~140 ms for the cross-attention of 8 images.
-// Here a WAVE owns a tile of 128 value positions of one (batch, head, level): lane == channel, and the tile lives in
-// 128 accumulator VGPRs per lane.  The wave scans every sampling point of its level (one point per lane, coalesced
-// loc / attw reads that stay L2-resident because all owners of a (batch, head) stream them together), queues the taps
-// that land in its tile (ballot-compacted into a small LDS queue), and drains the queue wave-wide: one coalesced read
-// of the query's gradient row per tap (16 in flight), then `acc[position] += g * coef` with the position as a
-// wave-uniform dynamic register index (s_set_gpr_idx — no LDS, no atomics).  Coarse levels have few tiles but receive
-// as many taps as the fine ones, so their query range is split over several waves (balanced tap count per wave) and
-// only those partial tiles meet through atomics in the (zero-filled) output: ~0.1 % of the original atomic traffic.
-#define MSDA_TILE 128
-#define MSDA_QCAP 384          // per-wave tap queue (drained when fewer than 256 free slots remain)
-#define MSDA_DRAIN_U 16        // gradient-row loads in flight per wave while draining
+// d_value without per-channel atomics: bin the taps by value tile, then accumulate each tile in REGISTERS.
+//
+// Measured on MI355X (scratch/ubench): the L2 executes fp32 atomics at ~1 dword/clock/channel (5.0 G 256-byte bursts/s
+// chip-wide, independent of footprint and scope) and LDS fp32 atomics are slower still (ds_add_f32: ~170 cycles per
+// wave-instruction per CU).  The direct scatter needs 64 dword atomics per tap, which pins the cross-attention of 8
+// images at ~140 ms.  Binning needs ONE integer atomic per tap:
+//   count : one sampling point per lane (perfectly coalesced loc / attw), 4 taps -> atomicAdd(count[bin], 1)
+//   scan  : exclusive prefix of the counts -> bin offsets, and the list of 4096-entry chunks
+//   fill  : same traversal, slot = offset[bin] + atomicAdd(cursor[bin], 1); entries[slot] = {query<<8 | pos, coef}
+//   drain : persistent waves pull chunks from a device-side work counter; lane == channel; entries are read
+//           64 at a time (coalesced) and broadcast with v_readlane; per tap ONE coalesced read of the query's gradient
+//           row (16 in flight) and `acc[pos] += g*coef` with pos as a wave-uniform dynamic register index
+//           (s_set_gpr_idx: the 64-position tile lives in 64 VGPRs per lane — no LDS, no atomics); a finished
+//           chunk is added to d_value with 128 atomic bursts, i.e. ~3 % of the original atomic traffic.
+// A bin = MSDA_TILE consecutive positions of one (batch, head, level).
+#define MSDA_TILE 64           // positions per bin: 64 accumulator VGPRs per lane, leaving room for 32 loads in flight
+#define MSDA_CHUNK 4096
+#define MSDA_DRAIN_U 32
 typedef float f32x32_t __attribute__((ext_vector_type(32)));
-struct MsdaTileMap { int first_block[MSDA_MAX_L + 1]; int splits[MSDA_MAX_L]; };   // owners of level l: tiles_l x splits_l
+struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; };     // tiles of level l: [first_tile[l], first_tile[l+1])
+
+struct MsdaWs {            // device workspace carved by the host wrapper
+  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int2* entries;   // ctrl[0] = total chunks, ctrl[1] = next
+};
+
+// Binning = a counting sort with workgroup-private LDS histograms (global integer atomics cost one L2 request per
+// lane: 8e8 of them took 45-70 ms; LDS counters are private to the CU).  grid = (segments, batch): a workgroup owns
+// MSDA_SEG consecutive sampling points of one image, one point per lane per iteration (perfectly coalesced loc / attw).
+//   COUNT: hist[head*ntiles + tile]++ in LDS, then the histogram is stored to seg_hist[b][seg][.] and added to cnt[bin]
+//   FILL : LDS cursors start at the segment's exclusive offsets (seg_hist rewritten in place by msda_segscan_k) and
+//          hand out slots: entries[slot] = {query << 8 | position in tile, coef}
+#define MSDA_SEG 65536
+template <bool FILL>
+__global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
+                                                   const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P) {
+  extern __shared__ int hist[];                          // [nH * ntiles]
+  const int ntiles = bins.first_tile[L];
+  const int nloc = nH * ntiles;
+  const int LP = L * P;
+  const int b = blockIdx.y, seg = blockIdx.x, nseg = gridDim.x;
+  const long npts_b = (long)Nq * nH * LP;
+  int* gh = ws.seg_hist + ((long)b * nseg + seg) * nloc;
+  for (int i = threadIdx.x; i < nloc; i += 256) hist[i] = FILL ? gh[i] : 0;
+  __syncthreads();
+  const long p_lo = (long)seg * MSDA_SEG, p_hi = min(npts_b, p_lo + MSDA_SEG);
+  for (long ib = p_lo + threadIdx.x; ib < p_hi; ib += 256) {
+    const int grp_b = (int)(ib / LP);                    // q*nH + head
+    const int lp = (int)(ib - (long)grp_b * LP);
+    const int l = lp / P;
+    const int q = grp_b / nH, head = grp_b - q * nH;
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const long pt = (long)b * npts_b + ib;
+    const float2 xy = ((const float2*)loc)[pt];
+    const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;
+    if (!(y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl)) continue;
+    const float xf = floorf(x), yf = floorf(y);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;
+    const float wgt = FILL ? attw[pt] : 0.f;
+    const int lb0 = head * ntiles + bins.first_tile[l];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+      if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {
+        const int pos = yy * Wl + xx;
+        const int lb = lb0 + pos / MSDA_TILE;
+        const int slot = atomicAdd(&hist[lb], 1);        // LDS
+        if (FILL) {
+          const float cf = wgt * (((t >> 1) ? ay : by) * ((t & 1) ? ax : bx));
+          ws.entries[slot] = make_int2((q << 8) | (pos % MSDA_TILE), __float_as_int(cf));
+        }
+      }
+    }
+  }
+  if (!FILL) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nloc; i += 256) {
+      const int c = hist[i];
+      gh[i] = c;
+      if (c) atomicAdd(&ws.cnt[b * nloc + i], c);
+    }
+  }
+}
+
+// seg_hist[b][seg][i] (counts) -> absolute first slot of segment `seg` in bin b*nloc+i
+__global__ void __launch_bounds__(256) msda_segscan_k(MsdaWs ws, int nloc, int nseg, int B) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * nloc) return;
+  const int b = (int)(i / nloc), li = (int)(i - (long)b * nloc);
+  int run = (int)ws.offset[i];
+  int* p = ws.seg_hist + (long)b * nseg * nloc + li;
+  for (int sgm = 0; sgm < nseg; ++sgm) { const int c = p[(long)sgm * nloc]; p[(long)sgm * nloc] = run; run += c; }
+}
+
+__global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
+  __shared__ long s_off[1024];
+  __shared__ int s_chk[1024];
+  __shared__ long carry_off;
+  __shared__ int carry_chk;
+  if (threadIdx.x == 0) { carry_off = 0; carry_chk = 0; }
+  __syncthreads();
+  for (int base = 0; base < nbins; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int c = i < nbins ? ws.cnt[i] : 0;
+    const int k = (c + MSDA_CHUNK - 1) / MSDA_CHUNK;
+    s_off[threadIdx.x] = c; s_chk[threadIdx.x] = k;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
+      long vo = 0; int vk = 0;
+      if ((int)threadIdx.x >= d) { vo = s_off[threadIdx.x - d]; vk = s_chk[threadIdx.x - d]; }
+      __syncthreads();
+      s_off[threadIdx.x] += vo; s_chk[threadIdx.x] += vk;
+      __syncthreads();
+    }
+    if (i < nbins) {
+      ws.offset[i] = carry_off + s_off[threadIdx.x] - c;
+      ws.chunk_first[i] = carry_chk + s_chk[threadIdx.x] - k;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) { carry_off += s_off[1023]; carry_chk += s_chk[1023]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { ws.chunk_first[nbins] = carry_chk; ws.ctrl[0] = carry_chk; ws.ctrl[1] = 0; }
+}
 
 template <typename T>
-__global__ void __launch_bounds__(256) msda_bwd_value_k(MsdaLevels lv, MsdaTileMap tm, const float* __restrict__ loc,
-                                                        const float* __restrict__ attw, const T* __restrict__ gout,
-                                                        float* __restrict__ d_value, int Nv, int Nq, int nH, int L, int P,
-                                                        int n_owner) {
-  __shared__ int q_key[4 * MSDA_QCAP];        // query << 8 | position in tile
-  __shared__ float q_coef[4 * MSDA_QCAP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int owner = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);     // wave-uniform
-  if (owner >= n_owner) return;
-  const int bh = blockIdx.y;
-  const int b = bh / nH, head = bh - b * nH;
-  int l = 0;
-  while (l + 1 < L && owner >= tm.first_block[l + 1]) ++l;
-  const int Hl = lv.H[l], Wl = lv.W[l];
-  const int nsplit = tm.splits[l];
-  const int bidx = owner - tm.first_block[l];
-  const int tile_lo = (bidx / nsplit) * MSDA_TILE;
-  const int split = bidx % nsplit;
-  const int tile_n = min(MSDA_TILE, Hl * Wl - tile_lo);
-  const int q_lo = (int)((long)Nq * split / nsplit), q_hi = (int)((long)Nq * (split + 1) / nsplit);
+__global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins, MsdaWs ws, const T* __restrict__ gout,
+                                                    float* __restrict__ d_value, int nbins, int Nv, int Nq, int nH, int L) {
+  const int lane = threadIdx.x & 63;
+  const int ntiles = bins.first_tile[L];
+  const int total = ws.ctrl[0];
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(&ws.ctrl[1], 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= total) break;
+    int lo = 0, hi = nbins;                               // largest bin with chunk_first[bin] <= item
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_first[mid] <= item) lo = mid; else hi = mid; }
+    const int bin = lo;
+    const int nchunk = ws.chunk_first[bin + 1] - ws.chunk_first[bin];
+    const int chunk = item - ws.chunk_first[bin];
+    const int cnt = ws.cnt[bin];
+    const int e_lo = chunk * MSDA_CHUNK, e_hi = min(cnt, e_lo + MSDA_CHUNK);
+    const int2* ent = ws.entries + ws.offset[bin];
+    const int bh = bin / ntiles, tile = bin - bh * ntiles;
+    const int b = bh / nH, head = bh - b * nH;
+    int l = 0;
+    while (l + 1 < L && tile >= bins.first_tile[l + 1]) ++l;
+    const int tile_lo = (tile - bins.first_tile[l]) * MSDA_TILE;
+    const int tile_n = min(MSDA_TILE, lv.H[l] * lv.W[l] - tile_lo);
+    const long rowbase = (long)b * Nq * nH + head;
 
-  f32x32_t a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int* mykey = q_key + wave * MSDA_QCAP;
-  float* mycoef = q_coef + wave * MSDA_QCAP;
-  int qcount = 0;                                                        // wave-uniform
-  const long rowbase = (long)b * Nq * nH + head;
-  const int LP = L * P;
-  const long total = (long)q_hi * P, first = (long)q_lo * P;
-  const float fW = (float)Wl, fH = (float)Hl;
-
-  // (macro, not a lambda: capturing the accumulator vectors by reference would force them into scratch memory)
-#define MSDA_DRAIN()                                                                                        \
-  do {                                                                                                      \
-    for (int e = 0; e < qcount; e += MSDA_DRAIN_U) {                                                        \
-      float g[MSDA_DRAIN_U];                                                                                \
-      int key[MSDA_DRAIN_U];                                                                                \
-      _Pragma("unroll") for (int k = 0; k < MSDA_DRAIN_U; ++k) {                                            \
-        const int ee = min(e + k, qcount - 1);                                                              \
-        key[k] = mykey[ee];                                                                                 \
-        const float cfk = (e + k < qcount) ? mycoef[ee] : 0.f;                                              \
-        g[k] = cfk * Ld1<T>::ld(gout + (rowbase + (long)(key[k] >> 8) * nH) * 64 + lane);                   \
-      }                                                                                                     \
-      _Pragma("unroll") for (int k = 0; k < MSDA_DRAIN_U; ++k) {                                            \
-        const int r = __builtin_amdgcn_readfirstlane(key[k]) & 0xff;                                        \
-        const int gsel = r >> 5, e5 = r & 31;                                                               \
-        if (gsel == 0) a0[e5] += g[k];                                                                      \
-        else if (gsel == 1) a1[e5] += g[k];                                                                 \
-        else if (gsel == 2) a2[e5] += g[k];                                                                 \
-        else a3[e5] += g[k];                                                                                \
-      }                                                                                                     \
-    }                                                                                                       \
-    qcount = 0;                                                                                             \
-  } while (0)
-  auto fetch = [&](long i, float& lx, float& ly, float& wgt) {
-    lx = 0.f; ly = -4.f; wgt = 0.f;                                      // rejected by the bounds test below
-    if (i < total) {
-      const int q = (int)(i / P);
-      const int p = (int)(i - (long)q * P);
-      const long row = rowbase + (long)q * nH;
-      const float2 xy = *(const float2*)(loc + row * (LP * 2) + (l * P + p) * 2);
-      lx = xy.x; ly = xy.y;
-      wgt = attw[row * LP + l * P + p];
-    }
-  };
-  float lx, ly, wgt;
-  fetch(first + lane, lx, ly, wgt);
-  for (long base = first; base < total; base += 64) {
-    float nlx, nly, nwgt;
-    fetch(base + 64 + lane, nlx, nly, nwgt);
-    const int q = (int)((base + lane) / P);
-    bool m[4] = {false, false, false, false};
-    int rel[4] = {0, 0, 0, 0};
-    float cf[4] = {0.f, 0.f, 0.f, 0.f};
-    const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
-    if (y > -1.f && x > -1.f && y < fH && x < fW) {
-      const float xf = floorf(x), yf = floorf(y);
-      const int x0 = (int)xf, y0 = (int)yf;
-      const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;
+    f32x32_t a0 = 0.f, a1 = 0.f;
+    for (int e0 = e_lo; e0 < e_hi; e0 += 64) {
+      int2 mine = make_int2(0, 0);                        // coef 0: harmless padding entry (query 0, position 0)
+      if (e0 + lane < e_hi) mine = ent[e0 + lane];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-        if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {
-          const int r = yy * Wl + xx - tile_lo;
-          if ((unsigned)r < (unsigned)tile_n) {
-            m[t] = true;
-            rel[t] = r;
-            cf[t] = wgt * (((t >> 1) ? ay : by) * ((t & 1) ? ax : bx));
+      for (int g4 = 0; g4 < 64 / MSDA_DRAIN_U; ++g4) {
+        if (e0 + g4 * MSDA_DRAIN_U < e_hi) {              // wave-uniform
+          float g[MSDA_DRAIN_U];
+          int key[MSDA_DRAIN_U];
+#pragma unroll
+          for (int k = 0; k < MSDA_DRAIN_U; ++k) {
+            key[k] = __builtin_amdgcn_readlane(mine.x, g4 * MSDA_DRAIN_U + k);
+            const float cf = __int_as_float(__builtin_amdgcn_readlane(mine.y, g4 * MSDA_DRAIN_U + k));
+            g[k] = cf * Ld1<T>::ld(gout + (rowbase + (long)(key[k] >> 8) * nH) * 64 + lane);
+          }
+#pragma unroll
+          for (int k = 0; k < MSDA_DRAIN_U; ++k) {
+            const int r = key[k] & 0xff;
+            const int e5 = r & 31;
+            if (r < 32) a0[e5] += g[k];
+            else a1[e5] += g[k];
           }
         }
       }
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const unsigned long long mask = __ballot(m[t]);
-      if (m[t]) {
-        const int slot = qcount + __popcll(mask & ((1ull << lane) - 1ull));
-        mykey[slot] = (q << 8) | rel[t];
-        mycoef[slot] = cf[t];
-      }
-      qcount += __popcll(mask);
-    }
-    if (qcount > MSDA_QCAP - 256) MSDA_DRAIN();
-    lx = nlx; ly = nly; wgt = nwgt;
-  }
-  MSDA_DRAIN();
-  float* dst = d_value + (((long)b * Nv + lv.start[l] + tile_lo) * nH + head) * 64 + lane;
-  const long pstride = (long)nH * 64;
+    float* dst = d_value + (((long)b * Nv + lv.start[l] + tile_lo) * nH + head) * 64 + lane;
+    const long pstride = (long)nH * 64;
 #define MSDA_FLUSH(vec, base)                                                       \
   _Pragma("unroll") for (int e = 0; e < 32; ++e) {                                   \
     if ((base) + e < tile_n) {                                                       \
-      if (nsplit == 1) dst[((base) + e) * pstride] = vec[e];                         \
+      if (nchunk == 1) dst[((base) + e) * pstride] = vec[e];                         \
       else atomicAdd(dst + ((base) + e) * pstride, vec[e]);                          \
     }                                                                                \
   }
-  MSDA_FLUSH(a0, 0) MSDA_FLUSH(a1, 32) MSDA_FLUSH(a2, 64) MSDA_FLUSH(a3, 96)
+    MSDA_FLUSH(a0, 0) MSDA_FLUSH(a1, 32)
 #undef MSDA_FLUSH
-#undef MSDA_DRAIN
+  }
+}
+
+static size_t msda_ws_layout(int nbins, long seg_hist_ints, long max_entries, char* base, MsdaWs* ws) {
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_cnt = carve((size_t)nbins * 4), o_chk = carve((size_t)(nbins + 1) * 4);
+  const size_t o_off = carve((size_t)(nbins + 1) * 8), o_ctrl = carve(16), o_sh = carve((size_t)seg_hist_ints * 4);
+  const size_t o_ent = carve((size_t)max_entries * 8);
+  if (ws) {
+    ws->cnt = (int*)(base + o_cnt); ws->chunk_first = (int*)(base + o_chk); ws->offset = (long*)(base + o_off);
+    ws->ctrl = (int*)(base + o_ctrl); ws->seg_hist = (int*)(base + o_sh); ws->entries = (int2*)(base + o_ent);
+  }
+  return off;
+}
+struct MsdaPlan { int ntiles, nloc, nseg, nbins; long max_entries; bool ok; };
+static MsdaPlan msda_plan(const MsdaBins& bins, int B, int Nq, int nH, int L, int P) {
+  MsdaPlan pl;
+  pl.ntiles = bins.first_tile[L];
+  pl.nloc = nH * pl.ntiles;
+  const long npts_b = (long)Nq * nH * L * P;
+  pl.nseg = (int)((npts_b + MSDA_SEG - 1) / MSDA_SEG);
+  pl.max_entries = (long)B * npts_b * 4;
+  const long nbins = (long)B * pl.nloc;
+  pl.nbins = (int)nbins;
+  pl.ok = nbins < (1L << 30) && Nq < (1 << 23) && pl.max_entries < (1L << 31) && (size_t)pl.nloc * 4 <= 60 * 1024 && B <= 65535;
+  return pl;
+}
+static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
+  int n = 0;
+  for (int l = 0; l < L; ++l) { bins.first_tile[l] = n; n += (lv.H[l] * lv.W[l] + MSDA_TILE - 1) / MSDA_TILE; }
+  bins.first_tile[L] = n;
+  return n;
 }
 
 static int msda_levels(const int* spatial_hw, int L, int Nv, MsdaLevels& lv) {
@@ -351,9 +539,19 @@ extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const float
   return GE_OK;
 }
 
+extern "C" size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P) {
+  MsdaLevels lv;
+  if (!spatial_hw || msda_levels(spatial_hw, L, Nv, lv)) return 0;
+  MsdaBins bins;
+  msda_bins(lv, L, bins);
+  const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
+  if (!pl.ok) return 0;
+  return msda_ws_layout(pl.nbins, (long)B * pl.nseg * pl.nloc, pl.max_entries, nullptr, nullptr);
+}
+
 extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out,
-                           float* d_value, float* d_loc, float* d_attw, int B, int Nv, int Nq, int nH, int L, int P,
-                           int dtype, void* stream) {
+                           float* d_value, float* d_loc, float* d_attw, void* workspace, size_t workspace_bytes,
+                           int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
   if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || !d_loc || !d_attw) return GE_ERR_BAD_ARG;
   if (B < 0 || Nv <= 0 || Nq < 0 || nH <= 0 || P <= 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
@@ -365,39 +563,51 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   hipStream_t s = ge_stream(stream);
   if (P != 4 && P != 8) return GE_ERR_UNSUPPORTED;
   if (dtype != GE_F32 && dtype != GE_BF16) return GE_ERR_UNSUPPORTED;
-  // Default: one pass, d_value through coalesced 256-byte fp32 atomic bursts (at the L2 atomic-unit limit).
-  // GE_MSDA_BWD=tile selects the experimental two-pass form: (1) d_loc / d_attw with reads only, (2) d_value by the
-  // register tile-owner scatter below (correct, currently slower: kept for the next round's profiling).
-  static const bool tile_mode = [] { const char* e = getenv("GE_MSDA_BWD"); return e && e[0] == 't'; }();
+  // With a workspace: d_loc / d_attw by a read-only pass, d_value by bin -> register-tile accumulation (see above).
+  // Without one: a single pass with coalesced 256-byte fp32 atomic bursts (bounded by the L2 atomic units).
 #define MSDA_BWD(TT, PP, AT)                                                                                               \
   msda_bwd_k<TT, PP, AT><<<blocks, 256, 0, s>>>((const TT*)value, lv, loc, attw, (const TT*)d_out, d_value, d_loc, d_attw, \
                                                 n_groups, Nv, Nq, nH, L)
 #define MSDA_BWD_P(TT, AT) do { if (P == 8) MSDA_BWD(TT, 8, AT); else MSDA_BWD(TT, 4, AT); } while (0)
-  if (!tile_mode) {
+  MsdaBins bins;
+  msda_bins(lv, L, bins);
+  const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
+  const long seg_ints = (long)B * pl.nseg * pl.nloc;
+  const bool binned = workspace && pl.ok && workspace_bytes >= msda_ws_layout(pl.nbins, seg_ints, pl.max_entries, nullptr, nullptr);
+  if (!binned) {
     if (dtype == GE_F32) MSDA_BWD_P(float, true); else MSDA_BWD_P(bf16_t, true);
     GE_LAUNCH_CHECK();
     return GE_OK;
   }
-  if (dtype == GE_F32) MSDA_BWD_P(float, false); else MSDA_BWD_P(bf16_t, false);
 #undef MSDA_BWD_P
 #undef MSDA_BWD
-  GE_LAUNCH_CHECK();
-  MsdaTileMap tm;
-  int ntiles = 0, max_tiles = 1;
-  for (int l = 0; l < L; ++l) max_tiles = std::max(max_tiles, (lv.H[l] * lv.W[l] + MSDA_TILE - 1) / MSDA_TILE);
-  for (int l = 0; l < L; ++l) {
-    const int tiles = (lv.H[l] * lv.W[l] + MSDA_TILE - 1) / MSDA_TILE;
-    tm.splits[l] = std::max(1, std::min(std::min(128, Nq), (max_tiles + tiles / 2) / tiles));
-    tm.first_block[l] = ntiles;
-    ntiles += tiles * tm.splits[l];
+  {
+    const unsigned lblocks = ge_blocks(n_groups, 16, 256 * 64);
+    if (dtype == GE_F32)
+      msda_bwd_lw_k<float><<<lblocks, 256, 0, s>>>((const float*)value, lv, loc, attw, (const float*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
+    else
+      msda_bwd_lw_k<bf16_t><<<lblocks, 256, 0, s>>>((const bf16_t*)value, lv, loc, attw, (const bf16_t*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
   }
-  tm.first_block[L] = ntiles;
-  if (Nq >= (1 << 23)) return GE_ERR_UNSUPPORTED;                   // query index is packed into 24 bits
-  dim3 grid((unsigned)((ntiles + 3) / 4), (unsigned)(B * nH));
+  GE_LAUNCH_CHECK();
+  const int nbins = pl.nbins;
+  MsdaWs ws;
+  msda_ws_layout(nbins, seg_ints, pl.max_entries, (char*)workspace, &ws);
+  hipError_t he = hipMemsetAsync(ws.cnt, 0, (size_t)nbins * 4, s);
+  if (he != hipSuccess) return (int)he;
+  dim3 hgrid((unsigned)pl.nseg, (unsigned)B);
+  const size_t hsmem = (size_t)pl.nloc * 4;
+  msda_hist_k<false><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P);
+  GE_LAUNCH_CHECK();
+  msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
+  GE_LAUNCH_CHECK();
+  msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.nloc, pl.nseg, B);
+  GE_LAUNCH_CHECK();
+  msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P);
+  GE_LAUNCH_CHECK();
   if (dtype == GE_F32)
-    msda_bwd_value_k<float><<<grid, 256, 0, s>>>(lv, tm, loc, attw, (const float*)d_out, d_value, Nv, Nq, nH, L, P, ntiles);
+    msda_drain_k<float><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
   else
-    msda_bwd_value_k<bf16_t><<<grid, 256, 0, s>>>(lv, tm, loc, attw, (const bf16_t*)d_out, d_value, Nv, Nq, nH, L, P, ntiles);
+    msda_drain_k<bf16_t><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

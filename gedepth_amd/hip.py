@@ -23,7 +23,8 @@ SIGNATURES = {
     'ge_window_attn_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'ge_window_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'ge_msda_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_bwd_workspace': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
+    'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_ground_embed_fwd': (_i, [_vp, _vp, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

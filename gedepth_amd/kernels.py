@@ -108,6 +108,8 @@ def window_attention(qkv, qkv_bias, bias_table, H, W, num_heads, shift, scale, v
 
 
 # ------------------------------------------------------------------------------------ MSDA
+MSDA_BINNED_BACKWARD = True     # False: single-pass fp32-atomic scatter (no workspace)
+
 def _levels(spatial_shapes):
     flat = [int(v) for hw in spatial_shapes for v in hw]
     return (ctypes.c_int * len(flat))(*flat), len(flat) // 2
@@ -146,10 +148,14 @@ class _MSDeformAttn(torch.autograd.Function):
         d_attw = torch.empty_like(attw)
         nbytes = (value.numel() * _es(value) + 2 * loc.numel() * 4 + 2 * attw.numel() * 4 + d_out.numel() * _es(d_out)
                   + d_value.numel() * 4)
-        PROFILER.run(f'msda_bwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(
-            hip.lib().ge_msda_bwd(hip.ptr(value), ctypes.cast(arr, ctypes.c_void_p), hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
-                                  hip.ptr(d_value), hip.ptr(d_loc), hip.ptr(d_attw), B, Nv, Nq, nH, L, P,
-                                  hip.dtype_code(value), hip.stream()), 'ge_msda_bwd'))
+        lib = hip.lib()
+        shapes_p = ctypes.cast(arr, ctypes.c_void_p)
+        ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P)) if MSDA_BINNED_BACKWARD else 0
+        ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8) if ws_bytes else None
+        PROFILER.run(f'msda_bwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}{" binned" if ws_bytes else ""}]', nbytes, lambda: hip.check(
+            lib.ge_msda_bwd(hip.ptr(value), shapes_p, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
+                            hip.ptr(d_value), hip.ptr(d_loc), hip.ptr(d_attw), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P,
+                            hip.dtype_code(value), hip.stream()), 'ge_msda_bwd'))
         return d_value.to(value.dtype), d_loc, d_attw, None
 
 

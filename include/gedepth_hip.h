@@ -76,10 +76,14 @@ int ge_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias
 int ge_msda_fwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, void* out,
                 int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 
-/* Backward.  d_value (B,Nv,nH,64) is ALWAYS f32 and must be zero-filled by the caller (fp32 atomics);
- * d_loc / d_attw are fully written. */
+/* Backward.  d_value (B,Nv,nH,64) is ALWAYS f32 and must be zero-filled by the caller; d_loc / d_attw are fully
+ * written.  `workspace` (>= ge_msda_bwd_workspace(...) bytes, caller-owned scratch) enables the binned scatter
+ * (one integer atomic per tap, tiles accumulated in registers); with workspace == NULL the scatter falls back to
+ * fp32 atomic bursts straight into d_value. */
+size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P);
 int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw,
                 const void* d_out, float* d_value, float* d_loc, float* d_attw,
+                void* workspace, size_t workspace_bytes,
                 int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -205,9 +205,14 @@ def _msda_inputs(seed, B=2, Nq=70, shapes=((11, 35), (6, 18), (3, 9), (2, 5))):
     return value, loc, aw, go, [tuple(s) for s in shapes]
 
 
-def test_msda_fp32_fwd_bwd(dev):
+@pytest.mark.parametrize('binned', [True, False])
+@pytest.mark.parametrize('shapes', [((11, 35), (6, 18), (3, 9), (2, 5)), ((40, 70), (20, 35), (10, 18), (5, 9))])
+def test_msda_fp32_fwd_bwd(dev, binned, shapes, monkeypatch):
+    """binned=True: count/scan/fill/drain scatter (one integer atomic per tap); False: fp32 atomic bursts."""
+    from gedepth_amd import kernels
     from gedepth_amd.kernels import ms_deform_attn
-    value, loc, aw, go, shapes = _msda_inputs(1)
+    monkeypatch.setattr(kernels, 'MSDA_BINNED_BACKWARD', binned)
+    value, loc, aw, go, shapes = _msda_inputs(1, B=2, Nq=300 if shapes[0][0] == 40 else 70, shapes=shapes)
     vc, lc, ac = (t.clone().requires_grad_(True) for t in (value, loc, aw))
     ref = O.msda_core(vc, shapes, lc, ac)
     ref.backward(go)
