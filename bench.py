@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--cudnn-benchmark', type=int, default=1, help='MIOpen find mode (configs: cudnn_benchmark = True)')
     return ap.parse_args()
 
 
@@ -46,7 +47,7 @@ def cpu_baseline(cfg_name, H, W):
     from oracle.fill import fill_state_dict
     from gedepth_amd.depth.models import build_depther
     from gedepth_amd.mmrt.config import Config
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)        # more threads only add synchronisation overhead for these op sizes
     torch.set_num_threads(cores)
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', cfg_name))
     cfg.model.pretrained = None
@@ -79,6 +80,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)   # default_runtime.py: cudnn_benchmark = True
 
     from gedepth_amd import hip, kernels
     from gedepth_amd.depth.datasets.synthetic import synthetic_batch

@@ -36,6 +36,18 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
+template <typename T> struct Vec4Raw;      // 4 channels, raw storage bits (no conversion): gather -> LDS staging
+template <> struct Vec4Raw<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ float4 ld(const float* p) { return *(const float4*)p; }
+  static __device__ __forceinline__ void st(float* p, const float4& v) { *(float4*)p = v; }
+};
+template <> struct Vec4Raw<bf16_t> {
+  typedef uint2 type;
+  static __device__ __forceinline__ uint2 ld(const bf16_t* p) { return *(const uint2*)p; }
+  static __device__ __forceinline__ void st(bf16_t* p, const uint2& v) { *(uint2*)p = v; }
+};
+
 __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 8, 64);
   v += __shfl_xor(v, 4, 64);
@@ -246,42 +258,83 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
     const T* vb = value + ((long)b * Nv * nH + head) * 64 + c4;
     float go[4];
     Vec4<T>::ld(gout + g_ * 64 + c4, go);
+#define MSDA_LW_POINT(j_, sv_, sx_, sy_)                                                                  \
+    {                                                                                                     \
+      const float2 xy = *(const float2*)(lp + 2 * (j_));                                                  \
+      const float wgt = ap[(j_)];                                                                         \
+      const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;                               \
+      float s_val = 0.f, s_dx = 0.f, s_dy = 0.f;                                                          \
+      if (live && y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl) {                               \
+        const float xf = floorf(x), yf = floorf(y);                                                       \
+        const int x0 = (int)xf, y0 = (int)yf;                                                             \
+        const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;                               \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+          const int xx = x0 + (t & 1), yy = y0 + (t >> 1);                                                \
+          if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {                                                 \
+            float v[4];                                                                                   \
+            Vec4<T>::ld(vl + ((long)yy * Wl + xx) * nH * 64, v);                                          \
+            const float gv = go[0] * v[0] + go[1] * v[1] + go[2] * v[2] + go[3] * v[3];                   \
+            const float wx = (t & 1) ? ax : bx, wy = (t >> 1) ? ay : by;                                  \
+            s_val += wy * wx * gv;                                                                        \
+            s_dx += ((t & 1) ? wy : -wy) * gv;                                                            \
+            s_dy += ((t >> 1) ? wx : -wx) * gv;                                                           \
+          }                                                                                               \
+        }                                                                                                 \
+      }                                                                                                   \
+      sv_ = s_val; sx_ = s_dx * (wgt * (float)Wl); sy_ = s_dy * (wgt * (float)Hl);                        \
+    }
     for (int l = 0; l < L; ++l) {
       const int Hl = lv.H[l], Wl = lv.W[l];
       const T* vl = vb + (long)lv.start[l] * nH * 64;
-      for (int p = 0; p < P; ++p) {
-        const int j = l * P + p;
-        const float2 xy = *(const float2*)(lp + 2 * j);
-        const float wgt = ap[j];
-        const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;
-        float s_val = 0.f, s_dx = 0.f, s_dy = 0.f;
-        if (live && y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl) {
-          const float xf = floorf(x), yf = floorf(y);
-          const int x0 = (int)xf, y0 = (int)yf;
-          const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;
+      if (P == 8) {
+        // 24 partial sums per level, reduce-scattered over the 16-lane group: 24 shuffles instead of 96
+        float part[24];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-            if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {
-              float v[4];
-              Vec4<T>::ld(vl + ((long)yy * Wl + xx) * nH * 64, v);
-              const float gv = go[0] * v[0] + go[1] * v[1] + go[2] * v[2] + go[3] * v[3];
-              const float wx = (t & 1) ? ax : bx, wy = (t >> 1) ? ay : by;
-              s_val += wy * wx * gv;
-              s_dx += ((t & 1) ? wy : -wy) * gv;
-              s_dy += ((t >> 1) ? wx : -wx) * gv;
-            }
+        for (int p = 0; p < 8; ++p) MSDA_LW_POINT(l * 8 + p, part[p], part[8 + p], part[16 + p])
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          const bool up = sub & 8;
+          const float send = up ? part[k] : part[k + 12], keep = up ? part[k + 12] : part[k];
+          part[k] = keep + __shfl_xor(send, 8, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const bool up = sub & 4;
+          const float send = up ? part[k] : part[k + 6], keep = up ? part[k + 6] : part[k];
+          part[k] = keep + __shfl_xor(send, 4, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const bool up = sub & 2;
+          const float send = up ? part[k] : part[k + 3], keep = up ? part[k + 3] : part[k];
+          part[k] = keep + __shfl_xor(send, 2, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) part[k] += __shfl_xor(part[k], 1, 64);
+        if (live && (sub & 1) == 0) {
+          const int base = ((sub >> 3) & 1) * 12 + ((sub >> 2) & 1) * 6 + ((sub >> 1) & 1) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int idx = base + k;
+            const int which = idx >> 3, j = l * 8 + (idx & 7);
+            if (which == 0) d_attw[g_ * (long)LP + j] = part[k];
+            else d_loc[(g_ * (long)LP + j) * 2 + (which - 1)] = part[k];
           }
         }
-        s_val = group16_sum(s_val);
-        s_dx = group16_sum(s_dx);
-        s_dy = group16_sum(s_dy);
-        if (live && sub == 0) {
-          d_attw[g_ * (long)LP + j] = s_val;
-          *(float2*)(d_loc + (g_ * (long)LP + j) * 2) = make_float2(s_dx * wgt * (float)Wl, s_dy * wgt * (float)Hl);
+      } else {
+        for (int p = 0; p < P; ++p) {
+          const int j = l * P + p;
+          float sv, sx, sy;
+          MSDA_LW_POINT(j, sv, sx, sy)
+          sv = group16_sum(sv); sx = group16_sum(sx); sy = group16_sum(sy);
+          if (live && sub == 0) {
+            d_attw[g_ * (long)LP + j] = sv;
+            *(float2*)(d_loc + (g_ * (long)LP + j) * 2) = make_float2(sx, sy);
+          }
         }
       }
     }
+#undef MSDA_LW_POINT
   }
 }
 
@@ -414,6 +467,7 @@ __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
 template <typename T>
 __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins, MsdaWs ws, const T* __restrict__ gout,
                                                     float* __restrict__ d_value, int nbins, int Nv, int Nq, int nH, int L) {
+  __shared__ __attribute__((aligned(16))) T stage_all[4 * 2 * 32 * 64];   // per wave: 2 buffers x 32 rows x 64 channels
   const int lane = threadIdx.x & 63;
   const int ntiles = bins.first_tile[L];
   const int total = ws.ctrl[0];
@@ -439,30 +493,48 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
     const long rowbase = (long)b * Nq * nH + head;
 
     f32x32_t a0 = 0.f, a1 = 0.f;
+    // Gather + accumulate, software-pipelined in half-blocks of 32 entries.
+    //  gather : a vector-memory instruction costs ~25-33 cycles per CU whatever it fetches, so rows are fetched FOUR per
+    //           instruction (16 lanes x 4 channels each, like the forward kernel) and parked in a wave-private LDS stage;
+    //  consume: lane == channel again: one ds_read per tap (cheap) and `acc[pos] += g * coef` with pos as a wave-uniform
+    //           dynamic register index.  Half-block n+1 is in flight while half-block n is consumed.
+    T* stage = stage_all + (size_t)(threadIdx.x >> 6) * (2 * 32 * 64);
+    const int gi = lane >> 4, sub4 = (lane & 15) * 4;
+    typename Vec4Raw<T>::type R[8];
+    int2 mine = make_int2(0, 0), nxt = make_int2(0, 0);     // coef 0: harmless padding entry (query 0, position 0)
+    if (e_lo + lane < e_hi) mine = ent[e_lo + lane];
+    // MINE/HB: entries [HB*32, HB*32+32) of the 64-entry register block MINE
+#define MSDA_GATHER(MINE, HB)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+    const int key = __shfl(MINE.x, (HB) * 32 + 4 * i + gi, 64);                                            \
+    R[i] = Vec4Raw<T>::ld(gout + (rowbase + (long)(key >> 8) * nH) * 64 + sub4);                           \
+  }
+#define MSDA_PARK(BUF)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i) Vec4Raw<T>::st(stage + ((BUF) * 32 + 4 * i + gi) * 64 + sub4, R[i]);
+#define MSDA_CONSUME(MINE, HB, BUF)                                                                        \
+  _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
+    const int key = __builtin_amdgcn_readlane(MINE.x, (HB) * 32 + k);                                      \
+    const float cf = __int_as_float(__builtin_amdgcn_readlane(MINE.y, (HB) * 32 + k));                     \
+    const float gv = cf * Ld1<T>::ld(stage + ((BUF) * 32 + k) * 64 + lane);                                \
+    const int r = key & 0xff;                                                                              \
+    const int e5 = r & 31;                                                                                 \
+    if (r < 32) a0[e5] += gv; else a1[e5] += gv;                                                           \
+  }
+    if (e_lo < e_hi) { MSDA_GATHER(mine, 0) MSDA_PARK(0) }
     for (int e0 = e_lo; e0 < e_hi; e0 += 64) {
-      int2 mine = make_int2(0, 0);                        // coef 0: harmless padding entry (query 0, position 0)
-      if (e0 + lane < e_hi) mine = ent[e0 + lane];
-#pragma unroll
-      for (int g4 = 0; g4 < 64 / MSDA_DRAIN_U; ++g4) {
-        if (e0 + g4 * MSDA_DRAIN_U < e_hi) {              // wave-uniform
-          float g[MSDA_DRAIN_U];
-          int key[MSDA_DRAIN_U];
-#pragma unroll
-          for (int k = 0; k < MSDA_DRAIN_U; ++k) {
-            key[k] = __builtin_amdgcn_readlane(mine.x, g4 * MSDA_DRAIN_U + k);
-            const float cf = __int_as_float(__builtin_amdgcn_readlane(mine.y, g4 * MSDA_DRAIN_U + k));
-            g[k] = cf * Ld1<T>::ld(gout + (rowbase + (long)(key[k] >> 8) * nH) * 64 + lane);
-          }
-#pragma unroll
-          for (int k = 0; k < MSDA_DRAIN_U; ++k) {
-            const int r = key[k] & 0xff;
-            const int e5 = r & 31;
-            if (r < 32) a0[e5] += g[k];
-            else a1[e5] += g[k];
-          }
-        }
-      }
+      nxt = make_int2(0, 0);
+      if (e0 + 64 + lane < e_hi) nxt = ent[e0 + 64 + lane];
+      MSDA_GATHER(mine, 1)                      // second half of this block in flight ...
+      MSDA_CONSUME(mine, 0, 0)                  // ... while the first half is consumed
+      MSDA_PARK(1)
+      if (e0 + 64 < e_hi) { MSDA_GATHER(nxt, 0) }
+      MSDA_CONSUME(mine, 1, 1)
+      if (e0 + 64 < e_hi) { MSDA_PARK(0) }
+      mine = nxt;
     }
+#undef MSDA_GATHER
+#undef MSDA_PARK
+#undef MSDA_CONSUME
     float* dst = d_value + (((long)b * Nv + lv.start[l] + tile_lo) * nH + head) * 64 + lane;
     const long pstride = (long)nH * 64;
 #define MSDA_FLUSH(vec, base)                                                       \

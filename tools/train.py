@@ -1,0 +1,87 @@
+#!/usr/bin/env python
+"""Train a depther — same CLI as the reference's tools/train.py:22-63 (config, --work-dir, --load-from, --resume-from,
+--no-validate, --seed, --options k=v, --launcher), on the MI355X runtime.
+
+    python tools/train.py configs/depthformer/depthformer_swint_v.py --synthetic 64 --options runner.max_iters=20
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
+
+The KITTI / DDAD data pipelines are the next scope row; until they land, ``--synthetic N`` trains on N
+seeded KITTI-shaped samples (gedepth_amd/depth/datasets/synthetic.py).
+"""
+import argparse
+import os
+import os.path as osp
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
+
+from gedepth_amd import __version__  # noqa: E402
+from gedepth_amd.depth.apis.train import set_random_seed, train_depther  # noqa: E402
+from gedepth_amd.depth.datasets.loader import SyntheticKITTI  # noqa: E402
+from gedepth_amd.depth.models import build_depther  # noqa: E402
+from gedepth_amd.mmrt.config import Config, DictAction  # noqa: E402
+from gedepth_amd.mmrt.ddp import init_dist  # noqa: E402
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description='Train a depther')
+    p.add_argument('config', help='train config file path')
+    p.add_argument('--work-dir', help='the dir to save logs and models')
+    p.add_argument('--load-from', help='the checkpoint file to load weights from')
+    p.add_argument('--resume-from', help='the checkpoint file to resume from')
+    p.add_argument('--no-validate', action='store_true')
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--deterministic', action='store_true')
+    p.add_argument('--options', nargs='+', default=None, help='override settings: k=v pairs')
+    p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic KITTI-shaped samples')
+    p.add_argument('--fp32', action='store_true', help='disable bf16 autocast')
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    cfg = Config.fromfile(args.config)
+    if args.options:
+        cfg.merge_from_dict(DictAction.parse(args.options))
+    cfg.work_dir = args.work_dir or cfg.get('work_dir') or osp.join('./work_dirs', osp.splitext(osp.basename(args.config))[0])
+    if args.load_from:
+        cfg.load_from = args.load_from
+    if args.resume_from:
+        cfg.resume_from = args.resume_from
+    if args.fp32:
+        cfg.amp = 'fp32'
+    distributed = args.launcher != 'none'
+    rank, local, world = init_dist(cfg.get('dist_params', {}).get('backend', 'nccl')) if distributed else (0, 0, 1)
+    if not distributed:
+        torch.cuda.set_device(0)
+    os.makedirs(cfg.work_dir, exist_ok=True)
+    if rank == 0:
+        cfg.dump(osp.join(cfg.work_dir, osp.basename(args.config)))
+    timestamp = time.strftime('%Y%m%d_%H%M%S', time.localtime())
+    if args.seed is not None:
+        set_random_seed(args.seed + rank, deterministic=args.deterministic)
+    cfg.seed = args.seed
+
+    pretrained = cfg.model.get('pretrained')
+    if pretrained and not osp.isfile(pretrained):
+        print(f'[train] pretrained weights {pretrained} not found: training from random init')
+        cfg.model.pretrained = None
+    model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    model.init_weights()
+    if args.synthetic <= 0:
+        raise NotImplementedError('real-dataset pipelines are the next scope row (SURVEY.md §8 f1); use --synthetic N')
+    h, w = cfg.get('crop_size', (352, 1120))
+    dataset = SyntheticKITTI(args.synthetic, h, w, adaptive='dynamic_pe_neck' in cfg.model, seed=1234)
+    meta = dict(gedepth_amd_version=__version__, config=cfg.pretty_text, seed=args.seed)
+    log = (lambda m: print(m, flush=True)) if rank == 0 else (lambda m: None)
+    train_depther(model, dataset, cfg, distributed=distributed, validate=not args.no_validate, timestamp=timestamp,
+                  meta=meta, logger=log)
+
+
+if __name__ == '__main__':
+    main()
