@@ -36,6 +36,30 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
+// CPL channels per lane: 16-byte accesses for both storage types (fp32: 4 channels, bf16: 8 channels)
+template <typename T> struct Lanes;
+template <> struct Lanes<float> { static constexpr int CPL = 4; };
+template <> struct Lanes<bf16_t> { static constexpr int CPL = 8; };
+template <typename T> struct VecL;
+template <> struct VecL<float> {
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) { Vec4<float>::ld(p, v); }
+  static __device__ __forceinline__ void st(float* p, const float v[4]) { Vec4<float>::st(p, v); }
+};
+template <> struct VecL<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
+    const uint4 t = *(const uint4*)p;
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
+    uint4 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+
 template <typename T> struct Vec4Raw;      // 4 channels, raw storage bits (no conversion): gather -> LDS staging
 template <> struct Vec4Raw<float> {
   typedef float4 type;
@@ -60,46 +84,46 @@ template <typename T>
 __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
                                                   const float* __restrict__ attw, T* __restrict__ out,
                                                   long n_groups, int Nv, int Nq, int nH, int L, int P) {
-  const int c4 = (threadIdx.x & 15) * 4;
-  const long grp0 = (long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-  const long gstride = (long)gridDim.x * (blockDim.x >> 4);
+  constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // lanes per (b,q,head) group: 16 (fp32) / 8 (bf16)
+  const int c0 = (threadIdx.x % G) * CPL;
+  const long grp0 = (long)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G);
+  const long gstride = (long)gridDim.x * (blockDim.x / G);
   for (long grp = grp0; grp < n_groups; grp += gstride) {   // grp = (b*Nq + q)*nH + head
     const int head = (int)(grp % nH);
     const long bq = grp / nH;
     const int b = (int)(bq / Nq);
     const float* lp = loc + grp * (long)(L * P * 2);
     const float* ap = attw + grp * (long)(L * P);
-    const T* vb = value + ((long)b * Nv * nH + head) * 64 + c4;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* vb = value + ((long)b * Nv * nH + head) * 64 + c0;
+    float acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
     for (int l = 0; l < L; ++l) {
       const int Hl = lv.H[l], Wl = lv.W[l];
       const T* vl = vb + (long)lv.start[l] * nH * 64;
       for (int p = 0; p < P; ++p) {
-        const float lx = lp[(l * P + p) * 2], ly = lp[(l * P + p) * 2 + 1];
+        const float2 xy = *(const float2*)(lp + (l * P + p) * 2);
         const float wgt = ap[l * P + p];
-        const float x = lx * (float)Wl - 0.5f, y = ly * (float)Hl - 0.5f;   // grid_sample, align_corners=False
+        const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;   // grid_sample, align_corners=False
         if (!(y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl)) continue;
         const float xf = floorf(x), yf = floorf(y);
-        const int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+        const int x0 = (int)xf, y0 = (int)yf;
         const float ax = x - xf, ay = y - yf;
-        const float w00 = (1.f - ay) * (1.f - ax) * wgt, w01 = (1.f - ay) * ax * wgt;
-        const float w10 = ay * (1.f - ax) * wgt, w11 = ay * ax * wgt;
-        float v[4];
-        if (y0 >= 0 && x0 >= 0) { Vec4<T>::ld(vl + ((long)y0 * Wl + x0) * nH * 64, v);
+        // clamp the addresses, zero the weights of out-of-range taps: four independent loads, no branches
+        const int xa = max(x0, 0), xb = min(x0 + 1, Wl - 1), ya = max(y0, 0), yb = min(y0 + 1, Hl - 1);
+        const float wxa = x0 >= 0 ? 1.f - ax : 0.f, wxb = x0 + 1 < Wl ? ax : 0.f;
+        const float wya = y0 >= 0 ? 1.f - ay : 0.f, wyb = y0 + 1 < Hl ? ay : 0.f;
+        float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
+        VecL<T>::ld(vl + ((long)ya * Wl + xa) * nH * 64, v00);
+        VecL<T>::ld(vl + ((long)ya * Wl + xb) * nH * 64, v01);
+        VecL<T>::ld(vl + ((long)yb * Wl + xa) * nH * 64, v10);
+        VecL<T>::ld(vl + ((long)yb * Wl + xb) * nH * 64, v11);
+        const float w00 = wya * wxa * wgt, w01 = wya * wxb * wgt, w10 = wyb * wxa * wgt, w11 = wyb * wxb * wgt;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] += w00 * v[i]; }
-        if (y0 >= 0 && x1 < Wl) { Vec4<T>::ld(vl + ((long)y0 * Wl + x1) * nH * 64, v);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] += w01 * v[i]; }
-        if (y1 < Hl && x0 >= 0) { Vec4<T>::ld(vl + ((long)y1 * Wl + x0) * nH * 64, v);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] += w10 * v[i]; }
-        if (y1 < Hl && x1 < Wl) { Vec4<T>::ld(vl + ((long)y1 * Wl + x1) * nH * 64, v);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] += w11 * v[i]; }
+        for (int i = 0; i < CPL; ++i) acc[i] += w00 * v00[i] + w01 * v01[i] + w10 * v10[i] + w11 * v11[i];
       }
     }
-    Vec4<T>::st(out + grp * 64 + c4, acc);
+    VecL<T>::st(out + grp * 64 + c0, acc);
   }
 }
 
@@ -241,10 +265,11 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
                                                      const float* __restrict__ attw, const T* __restrict__ gout,
                                                      float* __restrict__ d_loc, float* __restrict__ d_attw, long n_groups,
                                                      int Nv, int Nq, int nH, int L, int P) {
-  const int sub = threadIdx.x & 15;
-  const int c4 = sub * 4;
-  const long grp0 = (long)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);
-  const long gstride = (long)gridDim.x * (blockDim.x >> 4);
+  constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // 16-byte loads: 16 lanes (fp32) / 8 lanes (bf16) per group
+  const int sub = threadIdx.x % G;
+  const int c0 = sub * CPL;
+  const long grp0 = (long)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G);
+  const long gstride = (long)gridDim.x * (blockDim.x / G);
   const long iters = (n_groups + gstride - 1) / gstride;          // wave-uniform trip count: the shuffles need all lanes
   const int LP = L * P;
   for (long it = 0; it < iters; ++it) {
@@ -255,9 +280,9 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
     const int b = (int)((g_ / nH) / Nq);
     const float* lp = loc + g_ * (long)(LP * 2);
     const float* ap = attw + g_ * (long)LP;
-    const T* vb = value + ((long)b * Nv * nH + head) * 64 + c4;
-    float go[4];
-    Vec4<T>::ld(gout + g_ * 64 + c4, go);
+    const T* vb = value + ((long)b * Nv * nH + head) * 64 + c0;
+    float go[CPL];
+    VecL<T>::ld(gout + g_ * 64 + c0, go);
 #define MSDA_LW_POINT(j_, sv_, sx_, sy_)                                                                  \
     {                                                                                                     \
       const float2 xy = *(const float2*)(lp + 2 * (j_));                                                  \
@@ -268,18 +293,22 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
         const float xf = floorf(x), yf = floorf(y);                                                       \
         const int x0 = (int)xf, y0 = (int)yf;                                                             \
         const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;                               \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
-          const int xx = x0 + (t & 1), yy = y0 + (t >> 1);                                                \
-          if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {                                                 \
-            float v[4];                                                                                   \
-            Vec4<T>::ld(vl + ((long)yy * Wl + xx) * nH * 64, v);                                          \
-            const float gv = go[0] * v[0] + go[1] * v[1] + go[2] * v[2] + go[3] * v[3];                   \
-            const float wx = (t & 1) ? ax : bx, wy = (t >> 1) ? ay : by;                                  \
-            s_val += wy * wx * gv;                                                                        \
-            s_dx += ((t & 1) ? wy : -wy) * gv;                                                            \
-            s_dy += ((t >> 1) ? wx : -wx) * gv;                                                           \
-          }                                                                                               \
+        const int xa = max(x0, 0), xb = min(x0 + 1, Wl - 1), ya = max(y0, 0), yb = min(y0 + 1, Hl - 1);   \
+        const float m_xa = x0 >= 0 ? 1.f : 0.f, m_xb = x0 + 1 < Wl ? 1.f : 0.f;                           \
+        const float m_ya = y0 >= 0 ? 1.f : 0.f, m_yb = y0 + 1 < Hl ? 1.f : 0.f;                           \
+        float v00[CPL], v01[CPL], v10[CPL], v11[CPL];                                                     \
+        VecL<T>::ld(vl + ((long)ya * Wl + xa) * nH * 64, v00);                                            \
+        VecL<T>::ld(vl + ((long)ya * Wl + xb) * nH * 64, v01);                                            \
+        VecL<T>::ld(vl + ((long)yb * Wl + xa) * nH * 64, v10);                                            \
+        VecL<T>::ld(vl + ((long)yb * Wl + xb) * nH * 64, v11);                                            \
+        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;                                                 \
+        _Pragma("unroll") for (int i = 0; i < CPL; ++i) {                                                 \
+          d00 += go[i] * v00[i]; d01 += go[i] * v01[i]; d10 += go[i] * v10[i]; d11 += go[i] * v11[i];     \
         }                                                                                                 \
+        d00 *= m_ya * m_xa; d01 *= m_ya * m_xb; d10 *= m_yb * m_xa; d11 *= m_yb * m_xb;                    \
+        s_val = by * bx * d00 + by * ax * d01 + ay * bx * d10 + ay * ax * d11;                            \
+        s_dx = by * (d01 - d00) + ay * (d11 - d10);                                                       \
+        s_dy = bx * (d10 - d00) + ax * (d11 - d01);                                                       \
       }                                                                                                   \
       sv_ = s_val; sx_ = s_dx * (wgt * (float)Wl); sy_ = s_dy * (wgt * (float)Hl);                        \
     }
@@ -287,32 +316,34 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
       const int Hl = lv.H[l], Wl = lv.W[l];
       const T* vl = vb + (long)lv.start[l] * nH * 64;
       if (P == 8) {
-        // 24 partial sums per level, reduce-scattered over the 16-lane group: 24 shuffles instead of 96
+        // 24 partial sums per level, reduce-scattered over the lane group (24 -> 12 -> 6 -> 3 values per lane)
         float part[24];
 #pragma unroll
         for (int p = 0; p < 8; ++p) MSDA_LW_POINT(l * 8 + p, part[p], part[8 + p], part[16 + p])
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-          const bool up = sub & 8;
+          const bool up = sub & (G / 2);
           const float send = up ? part[k] : part[k + 12], keep = up ? part[k + 12] : part[k];
-          part[k] = keep + __shfl_xor(send, 8, 64);
+          part[k] = keep + __shfl_xor(send, G / 2, 64);
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          const bool up = sub & 4;
+          const bool up = sub & (G / 4);
           const float send = up ? part[k] : part[k + 6], keep = up ? part[k + 6] : part[k];
-          part[k] = keep + __shfl_xor(send, 4, 64);
+          part[k] = keep + __shfl_xor(send, G / 4, 64);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const bool up = sub & 2;
+          const bool up = sub & (G / 8);
           const float send = up ? part[k] : part[k + 3], keep = up ? part[k + 3] : part[k];
-          part[k] = keep + __shfl_xor(send, 2, 64);
+          part[k] = keep + __shfl_xor(send, G / 8, 64);
         }
+        if (G == 16) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) part[k] += __shfl_xor(part[k], 1, 64);
-        if (live && (sub & 1) == 0) {
-          const int base = ((sub >> 3) & 1) * 12 + ((sub >> 2) & 1) * 6 + ((sub >> 1) & 1) * 3;
+          for (int k = 0; k < 3; ++k) part[k] += __shfl_xor(part[k], 1, 64);
+        }
+        if (live && (G == 8 || (sub & 1) == 0)) {
+          const int base = ((sub / (G / 2)) & 1) * 12 + ((sub / (G / 4)) & 1) * 6 + ((sub / (G / 8)) & 1) * 3;
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int idx = base + k;
@@ -326,7 +357,8 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
           const int j = l * P + p;
           float sv, sx, sy;
           MSDA_LW_POINT(j, sv, sx, sy)
-          sv = group16_sum(sv); sx = group16_sum(sx); sy = group16_sum(sy);
+#pragma unroll
+          for (int o = G / 2; o > 0; o >>= 1) { sv += __shfl_xor(sv, o, 64); sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
           if (live && sub == 0) {
             d_attw[g_ * (long)LP + j] = sv;
             *(float2*)(d_loc + (g_ * (long)LP + j) * 2) = make_float2(sx, sy);
@@ -354,7 +386,7 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
 //           (s_set_gpr_idx: the 64-position tile lives in 64 VGPRs per lane — no LDS, no atomics); a finished
 //           chunk is added to d_value with 128 atomic bursts, i.e. ~3 % of the original atomic traffic.
 // A bin = MSDA_TILE consecutive positions of one (batch, head, level).
-#define MSDA_TILE 64           // positions per bin: 64 accumulator VGPRs per lane, leaving room for 32 loads in flight
+#define MSDA_TILE 32           // positions per bin = one 32-register accumulator block per lane (dynamic index: 11 instr/tap)
 #define MSDA_CHUNK 4096
 #define MSDA_DRAIN_U 32
 typedef float f32x32_t __attribute__((ext_vector_type(32)));
@@ -492,7 +524,7 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
     const int tile_n = min(MSDA_TILE, lv.H[l] * lv.W[l] - tile_lo);
     const long rowbase = (long)b * Nq * nH + head;
 
-    f32x32_t a0 = 0.f, a1 = 0.f;
+    f32x32_t a0 = 0.f;
     // Gather + accumulate, software-pipelined in half-blocks of 32 entries.
     //  gather : a vector-memory instruction costs ~25-33 cycles per CU whatever it fetches, so rows are fetched FOUR per
     //           instruction (16 lanes x 4 channels each, like the forward kernel) and parked in a wave-private LDS stage;
@@ -516,9 +548,7 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
     const int key = __builtin_amdgcn_readlane(MINE.x, (HB) * 32 + k);                                      \
     const float cf = __int_as_float(__builtin_amdgcn_readlane(MINE.y, (HB) * 32 + k));                     \
     const float gv = cf * Ld1<T>::ld(stage + ((BUF) * 32 + k) * 64 + lane);                                \
-    const int r = key & 0xff;                                                                              \
-    const int e5 = r & 31;                                                                                 \
-    if (r < 32) a0[e5] += gv; else a1[e5] += gv;                                                           \
+    a0[key & 31] += gv;   /* (two blocks + if/else made the compiler copy all 32 registers per tap) */      \
   }
     if (e_lo < e_hi) { MSDA_GATHER(mine, 0) MSDA_PARK(0) }
     for (int e0 = e_lo; e0 < e_hi; e0 += 64) {
@@ -544,7 +574,7 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
       else atomicAdd(dst + ((base) + e) * pstride, vec[e]);                          \
     }                                                                                \
   }
-    MSDA_FLUSH(a0, 0) MSDA_FLUSH(a1, 32)
+    MSDA_FLUSH(a0, 0)
 #undef MSDA_FLUSH
   }
 }
@@ -600,7 +630,7 @@ extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const float
   if (e) return e;
   const long n_groups = (long)B * Nq * nH;
   if (n_groups == 0) return GE_OK;
-  const unsigned blocks = ge_blocks(n_groups, 16, 1 << 22);
+  const unsigned blocks = ge_blocks(n_groups, dtype == GE_BF16 ? 32 : 16, 1 << 22);
   if (dtype == GE_F32)
     msda_fwd_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)value, lv, loc, attw, (float*)out, n_groups, Nv, Nq, nH, L, P);
   else if (dtype == GE_BF16)
@@ -654,7 +684,7 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
 #undef MSDA_BWD_P
 #undef MSDA_BWD
   {
-    const unsigned lblocks = ge_blocks(n_groups, 16, 256 * 64);
+    const unsigned lblocks = ge_blocks(n_groups, dtype == GE_BF16 ? 32 : 16, 256 * 64);
     if (dtype == GE_F32)
       msda_bwd_lw_k<float><<<lblocks, 256, 0, s>>>((const float*)value, lv, loc, attw, (const float*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
     else
