@@ -520,4 +520,123 @@ extern "C" int ge_adamw_step(float* param, const float* grad, float* exp_avg, fl
   return GE_OK;
 }
 
+// ============================================================================ bias + activation (NCHW)
+// y = act(x + b[c]) in place, act = leaky-relu with `slope` (0 -> ReLU, 1 -> identity).  Replaces the separate
+// broadcast bias add ATen issues after a MIOpen convolution plus the activation kernel
+// (mmcv ConvModule without norm: decode_heads/densedepth_head.py:14-27, necks/pemask_neck.py:36-42).
+// Backward: dx = dy * (y > 0 ? 1 : slope) and db[c] += sum dx in the same pass (block reduction + one atomic per block).
+template <typename T> struct V8;
+template <> struct V8<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
+    const uint4 t = *(const uint4*)p; const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
+    uint4 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+template <> struct V8<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+// grid: (chunks of one plane, N*C planes); HW % V8<T>::N == 0 (vector path) is checked by the launcher
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) bias_act_fwd_k(T* __restrict__ x, const float* __restrict__ bias, int C, long HW, float slope) {
+  const long plane = blockIdx.y;
+  const float b = bias[plane % C];
+  T* p = x + plane * HW;
+  constexpr int VN = V8<T>::N;
+  if (VEC) {
+    const long nv = HW / VN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float v[VN];
+      V8<T>::ld(p + i * VN, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) { const float t = v[k] + b; v[k] = t > 0.f ? t : t * slope; }
+      V8<T>::st(p + i * VN, v);
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+      const float t = Io<T>::ld(p + i) + b;
+      Io<T>::st(p + i, t > 0.f ? t : t * slope);
+    }
+  }
+}
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) bias_act_bwd_k(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                      float* __restrict__ dbias, int C, long HW, float slope) {
+  const long plane = blockIdx.y;
+  const T* gp = dy + plane * HW;
+  const T* yp = y + plane * HW;
+  T* dp = dx + plane * HW;
+  constexpr int VN = V8<T>::N;
+  float acc = 0.f;
+  if (VEC) {
+    const long nv = HW / VN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float g[VN], v[VN];
+      V8<T>::ld(gp + i * VN, g);
+      V8<T>::ld(yp + i * VN, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) { g[k] = v[k] > 0.f ? g[k] : g[k] * slope; acc += g[k]; }
+      V8<T>::st(dp + i * VN, g);
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+      float g = Io<T>::ld(gp + i);
+      g = Io<T>::ld(yp + i) > 0.f ? g : g * slope;
+      acc += g;
+      Io<T>::st(dp + i, g);
+    }
+  }
+  __shared__ float sm[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&dbias[plane % C], sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+template <typename T>
+static int bias_act_launch(bool fwd, void* x_or_dx, const void* dy, const void* y, const float* bias, float* dbias, int N, int C,
+                           long HW, float slope, hipStream_t s) {
+  const bool vec = (HW % V8<T>::N) == 0 && (((uintptr_t)x_or_dx | (uintptr_t)dy | (uintptr_t)y) & 15) == 0;
+  const long per_plane = vec ? HW / V8<T>::N : HW;
+  unsigned gx = (unsigned)((per_plane + 256 * 4 - 1) / (256 * 4));
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  dim3 grid(gx, (unsigned)(N * C));
+  if (fwd) {
+    if (vec) bias_act_fwd_k<T, true><<<grid, 256, 0, s>>>((T*)x_or_dx, bias, C, HW, slope);
+    else bias_act_fwd_k<T, false><<<grid, 256, 0, s>>>((T*)x_or_dx, bias, C, HW, slope);
+  } else {
+    if (vec) bias_act_bwd_k<T, true><<<grid, 256, 0, s>>>((const T*)dy, (const T*)y, (T*)x_or_dx, dbias, C, HW, slope);
+    else bias_act_bwd_k<T, false><<<grid, 256, 0, s>>>((const T*)dy, (const T*)y, (T*)x_or_dx, dbias, C, HW, slope);
+  }
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+extern "C" int ge_bias_act_fwd(void* x, const float* bias, int N, int C, long HW, float slope, int dtype, void* stream) {
+  if (!x || !bias || N < 0 || C <= 0 || HW < 0 || (long)N * C > 2147483647L) return GE_ERR_BAD_ARG;
+  if ((long)N * C * HW == 0) return GE_OK;
+  if (dtype == GE_F32) return bias_act_launch<float>(true, x, nullptr, nullptr, bias, nullptr, N, C, HW, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bias_act_launch<bf16_t>(true, x, nullptr, nullptr, bias, nullptr, N, C, HW, slope, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+extern "C" int ge_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, int N, int C, long HW, float slope,
+                               int dtype, void* stream) {
+  if (!dy || !y || !dx || !dbias || N < 0 || C <= 0 || HW < 0 || (long)N * C > 2147483647L) return GE_ERR_BAD_ARG;
+  if ((long)N * C * HW == 0) return GE_OK;
+  if (dtype == GE_F32) return bias_act_launch<float>(false, dx, dy, y, nullptr, dbias, N, C, HW, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bias_act_launch<bf16_t>(false, dx, dy, y, nullptr, dbias, N, C, HW, slope, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+
 extern "C" int ge_abi_version(void) { return 1; }

@@ -176,12 +176,12 @@ class HAHIHeteroNeck(BaseModule):
                                     reference_points=ref, spatial_shapes=shapes)
         else:
             fusion = query
-        fusion = fusion.permute(0, 2, 1).reshape(bs, c, h, w)
+        fusion = fusion.permute(0, 2, 1).unflatten(2, (h, w))        # view: the cat below is the only copy
         outs = [self.conv_fusion(torch.cat([fusion, feat_conv], dim=1))]
         start = 0
         for i, ft in enumerate(feats_trans):
             h, w = ft.shape[2:]
-            feat = src[:, start:start + h * w].permute(0, 2, 1).reshape(bs, self.embedding_dim, h, w)
+            feat = src[:, start:start + h * w].permute(0, 2, 1).unflatten(2, (h, w))
             start += h * w
             outs.append(self.trans_fusion[i](torch.cat([ft, feat], dim=1)))
         return tuple(outs)

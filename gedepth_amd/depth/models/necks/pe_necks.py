@@ -8,7 +8,7 @@ reference configs build unchanged, and lets Swin-T models (BASELINE configs #1/#
 import torch
 import torch.nn as nn
 
-from ....mmrt.bricks import BaseModule, xavier_init
+from ....mmrt.bricks import BaseModule, conv_bias_act, xavier_init
 from ...ops import resize
 from ..builder import NECKS
 
@@ -32,12 +32,16 @@ class _PETrunk(BaseModule):
                 xavier_init(m, distribution='uniform')
         self._is_init = True
 
+    @staticmethod
+    def _conv(conv, x):
+        return conv_bias_act(conv, x) if x.is_cuda else conv(x)
+
     def trunk(self, inputs):
         xs = inputs[::-1]                       # coarse -> fine
         size = xs[4].shape[2:]
         acc = None
         for i in range(5):
-            t = getattr(self, f'conv{i}')(xs[i])
+            t = self._conv(getattr(self, f'conv{i}'), xs[i])
             if i < 4:
                 t = resize(t, size=size, mode='bilinear', align_corners=True)
             acc = t if acc is None else acc + t
@@ -53,7 +57,7 @@ class LightPEMASKNeck(_PETrunk):
 
     def forward(self, inputs):
         x = self.trunk(inputs)
-        return self.sigmoid(self.convfinal(x)), x
+        return self.sigmoid(self._conv(self.convfinal, x)), x
 
 
 @NECKS.register_module()
@@ -63,4 +67,4 @@ class DynamicPENeckSOFT(_PETrunk):
         super().__init__(11, in_channels)
 
     def forward(self, inputs):
-        return self.convfinal(self.trunk(inputs))
+        return self._conv(self.convfinal, self.trunk(inputs))

@@ -27,6 +27,8 @@ SIGNATURES = {
     'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_bias_act_fwd': (_i, [_vp, _vp, _i, _i, _l, _f, _i, _vp]),
+    'ge_bias_act_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp]),
     'ge_ground_embed_fwd': (_i, [_vp, _vp, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_ground_embed_bwd': (_i, [_vp, _vp, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_ground_vanilla_fwd': (_i, [_vp, _vp, _l, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

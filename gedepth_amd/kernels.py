@@ -197,6 +197,40 @@ def bilinear_resize(x, size, align_corners=False):
     return _Bilinear.apply(x, Ho, Wo, bool(align_corners))
 
 
+# ------------------------------------------------------------------------- bias + activation
+class _BiasAct(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, bias, slope):
+        assert x.dim() == 4 and x.is_contiguous(), 'bias_act works in place on a contiguous NCHW conv output'
+        N, C, H, W = x.shape
+        b = _c(bias.detach().to(_f32))
+        PROFILER.run(f'bias_act_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 2 * x.numel() * _es(x), lambda: hip.check(
+            hip.lib().ge_bias_act_fwd(hip.ptr(x, name='x'), hip.ptr(b), N, C, H * W, slope, hip.dtype_code(x), hip.stream()),
+            'ge_bias_act_fwd'))
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        N, C, H, W = y.shape
+        dy = _c(dy.to(y.dtype))
+        dx = torch.empty_like(y)
+        db = torch.zeros(C, device=y.device, dtype=_f32)
+        PROFILER.run(f'bias_act_bwd[{N}x{C}x{H}x{W} {_tag(y)}]', 3 * y.numel() * _es(y), lambda: hip.check(
+            hip.lib().ge_bias_act_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(dx), hip.ptr(db), N, C, H * W, ctx.slope,
+                                      hip.dtype_code(y), hip.stream()), 'ge_bias_act_bwd'))
+        return dx, db, None
+
+
+def bias_act_(conv_out, bias, slope=1.0):
+    """In place on a fresh (bias-free) convolution output: leaky_relu(conv_out + bias[c], slope); slope 1 = no activation."""
+    return _BiasAct.apply(conv_out, bias, float(slope))
+
+
 # ------------------------------------------------------------------------ ground embedding
 def _plane_view(img, channel):
     """(base tensor for the pointer, batch stride in elements) of img[:, channel] (B,5,H,W contiguous)."""

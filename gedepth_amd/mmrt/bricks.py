@@ -194,13 +194,39 @@ class ConvModule(nn.Module):
         if self.with_norm:
             constant_init(self.norm, 1, bias=0)
 
+    def _fused_slope(self):
+        """leaky slope when conv bias + activation can run as one in-place HIP pass over the conv output, else None."""
+        if self.with_norm or self.conv.bias is None or type(self.conv) is not nn.Conv2d:
+            return None
+        if not self.with_activation:
+            return 1.0
+        if isinstance(self.activate, nn.LeakyReLU):
+            return float(self.activate.negative_slope)
+        if isinstance(self.activate, nn.ReLU):
+            return 0.0
+        return None
+
     def forward(self, x):
+        slope = self._fused_slope() if x.is_cuda else None
+        if slope is not None:
+            return conv_bias_act(self.conv, x, slope)
         x = self.conv(x)
         if self.with_norm:
             x = self.norm(x)
         if self.with_activation:
             x = self.activate(x)
         return x
+
+
+def conv_bias_act(conv, x, slope=1.0):
+    """``act(conv(x) + bias)`` with the bias add and the (leaky-)ReLU fused into one in-place HIP kernel over the
+    bias-free convolution output (MIOpen has no fused epilogue for these shapes; ATen would launch a broadcast add
+    and an activation kernel, and two more for their gradients)."""
+    from .. import kernels
+    y = conv._conv_forward(x, conv.weight, None)
+    if not y.is_contiguous():
+        y = y.contiguous()
+    return kernels.bias_act_(y, conv.bias, slope)
 
 
 def drop_path(x, drop_prob=0., training=False):

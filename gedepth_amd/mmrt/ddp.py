@@ -12,6 +12,8 @@ Replaces ``MMDistributedDataParallel`` as used by depth/apis/train.py:59-67 (ref
     per-GPU like the reference (SyncBN is configured but inactive there).
 Works with the ``gloo`` backend on CPU tensors for the world_size-2 tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -23,8 +25,10 @@ class FlatDDP(nn.Module):
         super().__init__()
         self.module, self.arena, self.group, self.overlap = module, arena, process_group, overlap
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # GE_DDP_FORCE=1 exercises the bucket / collective machinery on a single rank (1-GPU validation of the N-GPU path)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('GE_DDP_FORCE') == '1')
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
-        if self.world > 1 and broadcast:
+        if self.active and broadcast:
             dist.broadcast(arena.flat_param, src=0, group=process_group)        # C2: rank-0 state -> all
             for b in module.buffers():
                 if b.is_floating_point():
@@ -47,7 +51,7 @@ class FlatDDP(nn.Module):
         self._works = []
         self._next = 0
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for idx, p in enumerate(arena.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
         self._reset()
@@ -80,7 +84,7 @@ class FlatDDP(nn.Module):
 
     def finish(self):
         """Call after backward, before the optimizer: launches what is left, waits for all collectives."""
-        if self.world == 1:
+        if not self.active:
             return
         while self._next < len(self.buckets):            # parameters without a gradient this step, or overlap off
             self._launch(self._next)
@@ -111,11 +115,10 @@ class FlatDDP(nn.Module):
 def init_dist(backend='nccl'):
     """``torch.distributed`` bootstrap from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*);
     backend 'nccl' is RCCL on ROCm (configs/_base_/default_runtime.py: dist_params)."""
-    import os
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('GE_DDP_FORCE') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':

@@ -99,6 +99,17 @@ int ge_bilinear_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi,
                     int align_corners, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Bias + activation after a bias-free convolution, NCHW, in place: x = act(x + bias[c]) with
+ * act = leaky-relu(slope) (slope 0 = ReLU, 1 = identity).  Replaces the broadcast bias add + activation kernels of
+ * mmcv ConvModule without norm (decode_heads/densedepth_head.py:14-27) and of the PE-neck convs
+ * (necks/pemask_neck.py:36-42).  Backward: dx = dy * (y > 0 ? 1 : slope), dbias[c] += sum dx (dbias f32,
+ * zero-filled by the caller).  HW = H*W elements per (n, c) plane.
+ */
+int ge_bias_act_fwd(void* x, const float* bias, int N, int C, long HW, float slope, int dtype, void* stream);
+int ge_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, int N, int C, long HW, float slope,
+                    int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Ground-embedding prior (all fp32).
  * Adaptive: DepthEncoderDecoder.dynamic_pe + the y up-sampling of extract_feat
  * (depth/models/depther/encoder_decoder.py:79-102,111-114).  The bilinear (align_corners=False)

@@ -414,6 +414,50 @@ def test_depth_fuse(dev):
     close_scaled(pg.grad, pc.grad, what='d pe_mask')
     close_scaled(yg.grad, yc.grad, what='d y')
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (2, 16, 12, 16), (1, 3, 1, 1)])
+@pytest.mark.parametrize('slope', [1.0, 0.0, 0.01])
+def test_bias_act_fp32(dev, shape, slope):
+    """conv output + bias + (leaky) ReLU in one pass (ConvModule without norm, PE-neck convs) vs ATen."""
+    from gedepth_amd.kernels import bias_act_
+    g = gen(5)
+    x = torch.randn(*shape, generator=g)
+    b = torch.randn(shape[1], generator=g)
+    go = torch.randn(*shape, generator=g)
+    xc, bc = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    t = xc + bc.view(1, -1, 1, 1)
+    ref = t if slope == 1.0 else F.leaky_relu(t, slope)
+    ref.backward(go)
+    xg, bg = x.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = bias_act_(xg * 1.0, bg, slope)          # in place on a non-leaf, like a conv output
+    out.backward(go.to(dev))
+    close(out, ref, what='out')
+    close(xg.grad, xc.grad, what='dx')
+    close_scaled(bg.grad, bc.grad, what='dbias')
+
+
+@pytest.mark.gpu
+def test_conv_module_fused_bias_act_bf16(dev):
+    """ConvModule(conv+bias+LeakyReLU) through the fused kernel under autocast vs the unfused ATen sequence."""
+    from gedepth_amd.mmrt.bricks import ConvModule
+    torch.manual_seed(0)
+    m = ConvModule(8, 16, 3, padding=1, act_cfg=dict(type='LeakyReLU', negative_slope=0.01)).to(dev)
+    x = torch.randn(2, 8, 24, 40, device=dev)
+    go = torch.randn(2, 16, 24, 40, device=dev)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = m(x)
+    assert out.dtype == torch.bfloat16
+    out.float().backward(go)
+    gw, gb = m.conv.weight.grad.clone(), m.conv.bias.grad.clone()
+    m.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):          # same bf16 convolution, epilogue by ATen in fp32
+        y = F.conv2d(x, m.conv.weight, None, padding=1)
+    ref = F.leaky_relu(y.float() + m.conv.bias.view(1, -1, 1, 1), 0.01)
+    ref.backward(go)
+    assert (out.float() - ref).abs().max() <= 2 ** -8 * ref.abs().max()            # one bf16 rounding of the output
+    assert (gb - m.conv.bias.grad).norm() <= 1e-2 * m.conv.bias.grad.norm()         # dy rounded to bf16
+    assert (gw - m.conv.weight.grad).norm() <= 1e-2 * m.conv.weight.grad.norm()
+
 
 def test_silog(dev, golden):
     from gedepth_amd.kernels import silog_loss
