@@ -34,6 +34,28 @@ template <> struct Io<bf16_t> {
   static __device__ __forceinline__ float rt(float v) { return bf2f(f2bf(v)); }
 };
 
+// 16-byte vectors of the storage type, widened to fp32 registers (8 bf16 or 4 f32 per lane and instruction)
+template <typename T> struct V8;
+template <> struct V8<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
+    const uint4 t = *(const uint4*)p; const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
+    uint4 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+template <> struct V8<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
 // F.interpolate(mode='bilinear') source-index rule (scale from sizes, not from scale_factor).
 struct Lerp { int i0, i1; float w0, w1; };
 __device__ __forceinline__ float ge_scale(int in, int out, bool align) {

@@ -525,27 +525,6 @@ extern "C" int ge_adamw_step(float* param, const float* grad, float* exp_avg, fl
 // broadcast bias add ATen issues after a MIOpen convolution plus the activation kernel
 // (mmcv ConvModule without norm: decode_heads/densedepth_head.py:14-27, necks/pemask_neck.py:36-42).
 // Backward: dx = dy * (y > 0 ? 1 : slope) and db[c] += sum dx in the same pass (block reduction + one atomic per block).
-template <typename T> struct V8;
-template <> struct V8<bf16_t> {
-  static constexpr int N = 8;
-  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
-    const uint4 t = *(const uint4*)p; const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
-    uint4 t;
-    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-    *(uint4*)p = t;
-  }
-};
-template <> struct V8<float> {
-  static constexpr int N = 4;
-  static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-};
-
 // grid: (chunks of one plane, N*C planes); HW % V8<T>::N == 0 (vector path) is checked by the launcher
 template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) bias_act_fwd_k(T* __restrict__ x, const float* __restrict__ bias, int C, long HW, float slope) {

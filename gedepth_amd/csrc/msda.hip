@@ -713,3 +713,167 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
+
+// ============================================================================ sampling-location / weight preparation
+// One pass from the raw outputs of the `sampling_offsets` and `attention_weights` linears to the fp32 tensors the
+// sampling kernels read (mmcv MultiScaleDeformableAttention.forward: view -> softmax over L*P -> offset_normalizer
+// -> reference_points + offsets / normalizer):
+//   loc [b,q,h,l,p,:] = ref[b,q,l,:] + off_raw[b,q,(h,l,p,:)] / (W_l, H_l)
+//   attw[b,q,h,l,p]   = softmax over (l,p) of logit_raw[b,q,(h,l,p)]
+// One thread per (b,q,h,l) handles its P points; the softmax statistics cross the L = 4 neighbouring lanes with
+// DPP-style shuffles.  Replaces two dtype casts, a divide, an add and a softmax (each a full pass over 0.8-1.6 GB at
+// the KITTI shape) and their five backward passes.
+template <typename T, int K>
+__device__ __forceinline__ void ld_run(const T* p, float* v) {       // K contiguous elements, 16-byte vectors when K allows
+  constexpr int VN = V8<T>::N;
+  if constexpr (K % VN == 0) {
+#pragma unroll
+    for (int i = 0; i < K; i += VN) V8<T>::ld(p + i, v + i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; ++i) v[i] = Io<T>::ld(p + i);
+  }
+}
+template <typename T, int K>
+__device__ __forceinline__ void st_run(T* p, const float* v) {
+  constexpr int VN = V8<T>::N;
+  if constexpr (K % VN == 0) {
+#pragma unroll
+    for (int i = 0; i < K; i += VN) V8<T>::st(p + i, v + i);
+  } else {
+#pragma unroll
+    for (int i = 0; i < K; ++i) Io<T>::st(p + i, v[i]);
+  }
+}
+
+template <typename T, int P>
+__global__ void __launch_bounds__(256) msda_prep_fwd_k(const T* __restrict__ off_raw, long off_ld, const T* __restrict__ logit_raw,
+                                                       long logit_ld, const float* __restrict__ ref, long ref_sb, long ref_sq,
+                                                       long ref_sl, MsdaLevels lv, float* __restrict__ loc, float* __restrict__ attw,
+                                                       long total, int Nq, int nH) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int l = (int)(t & 3);
+    const long g = t >> 2;
+    const int h = (int)(g % nH);
+    const long row = g / nH;
+    const long b = row / Nq, q = row - b * Nq;
+    float off[2 * P], lg[P];
+    ld_run<T, 2 * P>(off_raw + row * off_ld + ((long)h * 4 + l) * (2 * P), off);
+    ld_run<T, P>(logit_raw + row * logit_ld + ((long)h * 4 + l) * P, lg);
+    const float* rp = ref + b * ref_sb + q * ref_sq + l * ref_sl;
+    const float rx = rp[0], ry = rp[1];
+    const float W = (float)lv.W[l], H = (float)lv.H[l];
+    float m = lg[0];
+#pragma unroll
+    for (int i = 1; i < P; ++i) m = fmaxf(m, lg[i]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) { lg[i] = expf(lg[i] - m); s += lg[i]; }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    float o[2 * P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) { o[2 * i] = rx + off[2 * i] / W; o[2 * i + 1] = ry + off[2 * i + 1] / H; lg[i] = lg[i] / s; }
+    st_run<float, 2 * P>(loc + t * (2 * P), o);
+    st_run<float, P>(attw + t * P, lg);
+  }
+}
+
+// d_off_raw = d_loc / (W_l, H_l);  d_logit = attw * (d_attw - sum_{l,p} attw * d_attw);  d_ref[b,q,l,:] = sum_{h,p} d_loc
+template <typename T, int P>
+__global__ void __launch_bounds__(256) msda_prep_bwd_k(const float* __restrict__ d_loc, const float* __restrict__ d_attw,
+                                                       const float* __restrict__ attw, MsdaLevels lv, T* __restrict__ d_off_raw,
+                                                       long off_ld, T* __restrict__ d_logit_raw, long logit_ld,
+                                                       float* __restrict__ d_ref, long total, int Nq, int nH) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int l = (int)(t & 3);
+    const long g = t >> 2;
+    const int h = (int)(g % nH);
+    const long row = g / nH;
+    float dl[2 * P], da[P], a[P];
+    ld_run<float, 2 * P>(d_loc + t * (2 * P), dl);
+    ld_run<float, P>(d_attw + t * P, da);
+    ld_run<float, P>(attw + t * P, a);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; ++i) s += a[i] * da[i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+#pragma unroll
+    for (int i = 0; i < P; ++i) da[i] = a[i] * (da[i] - s);
+    if (d_ref) {                                   // nH * 4 lanes of one query are adjacent (launcher checks nH in {1,2,4,8,16})
+      float sx = 0.f, sy = 0.f;
+#pragma unroll
+      for (int i = 0; i < P; ++i) { sx += dl[2 * i]; sy += dl[2 * i + 1]; }
+      for (int o = 4; o < 4 * nH; o <<= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+      if (h == 0) { d_ref[(row * 4 + l) * 2] = sx; d_ref[(row * 4 + l) * 2 + 1] = sy; }
+    }
+    const float iW = (float)lv.W[l], iH = (float)lv.H[l];
+#pragma unroll
+    for (int i = 0; i < P; ++i) { dl[2 * i] = dl[2 * i] / iW; dl[2 * i + 1] = dl[2 * i + 1] / iH; }
+    st_run<T, 2 * P>(d_off_raw + row * off_ld + ((long)h * 4 + l) * (2 * P), dl);
+    st_run<T, P>(d_logit_raw + row * logit_ld + ((long)h * 4 + l) * P, da);
+  }
+}
+
+static int prep_levels(const int* spatial_hw, int L, MsdaLevels& lv) {
+  if (L != 4) return GE_ERR_UNSUPPORTED;                                  // the 4-lane softmax exchange is the level axis
+  for (int l = 0; l < L; ++l) {
+    lv.H[l] = spatial_hw[2 * l]; lv.W[l] = spatial_hw[2 * l + 1]; lv.start[l] = 0;
+    if (lv.H[l] <= 0 || lv.W[l] <= 0) return GE_ERR_BAD_ARG;
+  }
+  return GE_OK;
+}
+static bool prep_aligned(const void* a, long a_ld, const void* b, long b_ld, int esize) {
+  const long v = 16 / esize;
+  return ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0 && a_ld % v == 0 && b_ld % v == 0;
+}
+
+extern "C" int ge_msda_prep_fwd(const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
+                                long ref_sb, long ref_sq, long ref_sl, const int* spatial_hw, float* loc, float* attw, int B,
+                                int Nq, int nH, int L, int P, int dtype, void* stream) {
+  if (!off_raw || !logit_raw || !ref || !spatial_hw || !loc || !attw || B < 0 || Nq < 0 || nH <= 0) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = prep_levels(spatial_hw, L, lv);
+  if (e) return e;
+  if (P != 4 && P != 8) return GE_ERR_UNSUPPORTED;
+  if (!prep_aligned(off_raw, off_ld, logit_raw, logit_ld, dtype == GE_BF16 ? 2 : 4)) return GE_ERR_BAD_ARG;
+  const long total = (long)B * Nq * nH * 4;
+  if (total == 0) return GE_OK;
+  const unsigned blocks = ge_blocks(total, 256, 1 << 20);
+  hipStream_t s = ge_stream(stream);
+#define GE_PREP(T, PP) msda_prep_fwd_k<T, PP><<<blocks, 256, 0, s>>>((const T*)off_raw, off_ld, (const T*)logit_raw, logit_ld, ref, \
+                                                                      ref_sb, ref_sq, ref_sl, lv, loc, attw, total, Nq, nH)
+  if (dtype == GE_F32) { if (P == 8) GE_PREP(float, 8); else GE_PREP(float, 4); }
+  else if (dtype == GE_BF16) { if (P == 8) GE_PREP(bf16_t, 8); else GE_PREP(bf16_t, 4); }
+  else return GE_ERR_UNSUPPORTED;
+#undef GE_PREP
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+extern "C" int ge_msda_prep_bwd(const float* d_loc, const float* d_attw, const float* attw, const int* spatial_hw, void* d_off_raw,
+                                long off_ld, void* d_logit_raw, long logit_ld, float* d_ref, int B, int Nq, int nH, int L, int P,
+                                int dtype, void* stream) {
+  if (!d_loc || !d_attw || !attw || !spatial_hw || !d_off_raw || !d_logit_raw || B < 0 || Nq < 0 || nH <= 0) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = prep_levels(spatial_hw, L, lv);
+  if (e) return e;
+  if (P != 4 && P != 8) return GE_ERR_UNSUPPORTED;
+  if (d_ref && !(nH == 1 || nH == 2 || nH == 4 || nH == 8 || nH == 16)) return GE_ERR_UNSUPPORTED;
+  if (!prep_aligned(d_off_raw, off_ld, d_logit_raw, logit_ld, dtype == GE_BF16 ? 2 : 4)) return GE_ERR_BAD_ARG;
+  const long total = (long)B * Nq * nH * 4;
+  if (total == 0) return GE_OK;
+  const unsigned blocks = ge_blocks(total, 256, 1 << 20);
+  hipStream_t s = ge_stream(stream);
+#define GE_PREP(T, PP) msda_prep_bwd_k<T, PP><<<blocks, 256, 0, s>>>(d_loc, d_attw, attw, lv, (T*)d_off_raw, off_ld, (T*)d_logit_raw, \
+                                                                      logit_ld, d_ref, total, Nq, nH)
+  if (dtype == GE_F32) { if (P == 8) GE_PREP(float, 8); else GE_PREP(float, 4); }
+  else if (dtype == GE_BF16) { if (P == 8) GE_PREP(bf16_t, 8); else GE_PREP(bf16_t, 4); }
+  else return GE_ERR_UNSUPPORTED;
+#undef GE_PREP
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}

@@ -13,8 +13,9 @@ the embeddings / pixel-centre points are cached per shape, and the sampling core
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
-from ....kernels import ms_deform_attn
+from ....kernels import concat_tokens_map, ms_deform_attn, msda_prepare, tokens_from_map
 from ....mmrt import bricks
 from ....mmrt.bricks import BaseModule, ConvModule, build_positional_encoding, xavier_init
 from ..builder import ATTENTION, NECKS
@@ -49,16 +50,11 @@ class MultiScaleDeformableAttention(BaseModule):
         xavier_init(self.output_proj, distribution='uniform', bias=0.)
         self._is_init = True
 
-    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
-        if value is None:
-            value = query
-        if identity is None:
-            identity = query                      # BEFORE the positional embedding is added
-        if query_pos is not None:
-            query = query + query_pos
-        if not self.batch_first:
-            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+    def _attend(self, query, value, reference_points, spatial_shapes, key_padding_mask=None):
+        """query (B,Nq,C) with the positional embedding already added, value (B,Nv,C) -> output_proj(sampled) (B,Nq,C).
+
+        The two query linears run as ONE GEMM on concatenated weights (their input is the same 0.4-0.8 GB tensor), and
+        view / softmax / normaliser / reference-point arithmetic is one HIP pass (kernels.msda_prepare)."""
         bs, num_query, _ = query.shape
         num_value = value.shape[1]
         if torch.is_tensor(spatial_shapes):
@@ -71,17 +67,37 @@ class MultiScaleDeformableAttention(BaseModule):
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.view(bs, num_value, self.num_heads, -1)
         nH, L, P = self.num_heads, self.num_levels, self.num_points
-        offsets = self.sampling_offsets(query).float().view(bs, num_query, nH, L, P, 2)
-        weights = self.attention_weights(query).float().view(bs, num_query, nH, L * P).softmax(-1)
-        weights = weights.view(bs, num_query, nH, L, P)
-        # sampling locations stay fp32 (pixel coordinates up to ~1000 need > 8 mantissa bits)
-        normalizer = torch.tensor([[w, h] for h, w in spatial_shapes], dtype=torch.float32, device=query.device)
-        loc = reference_points.float()[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+        b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+        raw = F.linear(query, w, b)                           # (B, Nq, nH*L*P*2 + nH*L*P)
+        # sampling locations / weights are fp32 (pixel coordinates up to ~1000 need > 8 mantissa bits)
+        loc, weights = msda_prepare(raw, reference_points.expand(bs, num_query, L, 2), spatial_shapes, nH, L, P)
         out = ms_deform_attn(value, spatial_shapes, loc, weights)
-        out = self.output_proj(out)
+        return self.output_proj(out)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query                      # BEFORE the positional embedding is added
+        if query_pos is not None:
+            query = query + query_pos.to(query.dtype)
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        out = self._attend(query, value, reference_points, spatial_shapes, key_padding_mask)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         return self.dropout(out) + identity
+
+    def forward_map(self, fmap, pos_map, value, reference_points, spatial_shapes, concat_with):
+        """Cross-attention with a feature-map query (hahi.py:303-333): query = tokens(fmap) + pos, identity = fmap, and the
+        result returned as ``torch.cat([to_map(dropout(out) + identity), concat_with], 1)``.  The two layout changes carry
+        the position add, the dropout, the residual and the concat write (gedepth_amd/csrc/neck.hip)."""
+        query = tokens_from_map(fmap, pos_map)
+        out = self._attend(query, value, reference_points, spatial_shapes)
+        p = self.dropout.p if self.training else 0.0
+        return concat_tokens_map(out, concat_with, identity=fmap, tokens_first=True, p_drop=p)
 
 
 @NECKS.register_module()
@@ -166,22 +182,19 @@ class HAHIHeteroNeck(BaseModule):
 
         conv_skip = self.conv_proj(feat_conv)
         _, c, h, w = conv_skip.shape
-        query = conv_skip.flatten(2).transpose(1, 2)
-        query_embed = self.conv_positional_encoding.grid(h, w, dev).flatten(2).transpose(1, 2)
         if self.cross_att:
-            # content-independent reference points: one (1, Nq, 2) evaluation, broadcast over batch and levels
-            ref = self.reference_points(query_embed.float()).sigmoid()
+            pos_map = self.conv_positional_encoding.grid(h, w, dev)                     # (1, C, h, w) fp32, cached
+            # content-independent reference points: one fp32 (1, Nq, 2) evaluation, broadcast over batch and levels
+            with torch.autocast('cuda', enabled=False):
+                ref = self.reference_points(pos_map.flatten(2).transpose(1, 2)).sigmoid()
             ref = ref[:, :, None, :].expand(bs, -1, len(shapes), 2)
-            fusion = self.multi_att(query, value=src, identity=None, query_pos=query_embed.expand(bs, -1, -1),
-                                    reference_points=ref, spatial_shapes=shapes)
+            fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv)
         else:
-            fusion = query
-        fusion = fusion.permute(0, 2, 1).unflatten(2, (h, w))        # view: the cat below is the only copy
-        outs = [self.conv_fusion(torch.cat([fusion, feat_conv], dim=1))]
+            fused = torch.cat([conv_skip, feat_conv], dim=1)
+        outs = [self.conv_fusion(fused)]
         start = 0
         for i, ft in enumerate(feats_trans):
             h, w = ft.shape[2:]
-            feat = src[:, start:start + h * w].permute(0, 2, 1).unflatten(2, (h, w))
+            outs.append(self.trans_fusion[i](concat_tokens_map(src[:, start:start + h * w], ft, tokens_first=False)))
             start += h * w
-            outs.append(self.trans_fusion[i](torch.cat([ft, feat], dim=1)))
         return tuple(outs)

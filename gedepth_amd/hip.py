@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libgedepth_hip.so')
 GE_F32, GE_BF16 = 0, 1
 
 _c = ctypes
-_vp, _i, _f, _l, _d, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_double, _c.c_size_t
+_vp, _i, _f, _l, _d, _sz, _u64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_long, _c.c_double, _c.c_size_t, _c.c_ulonglong
 
 # name -> (restype, argtypes): mirrors include/gedepth_hip.h one to one
 SIGNATURES = {
@@ -25,6 +25,10 @@ SIGNATURES = {
     'ge_msda_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_workspace': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_prep_fwd': (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_prep_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_tokens_from_map': (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _l, _f, _u64, _i, _vp]),
+    'ge_map_from_tokens': (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _l, _f, _u64, _i, _vp]),
     'ge_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bias_act_fwd': (_i, [_vp, _vp, _i, _i, _l, _f, _i, _vp]),

@@ -164,6 +164,164 @@ def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights)
     return _MSDeformAttn.apply(value, sampling_locations, attention_weights, spatial_shapes)
 
 
+class _MSDAPrep(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, raw, ref, spatial_shapes, nH, L, P):
+        raw = _c(raw)
+        B, Nq, ld = raw.shape
+        n_off, n_log = nH * L * P * 2, nH * L * P
+        assert ld == n_off + n_log, 'raw = [sampling_offsets | attention_weights] columns of one GEMM'
+        ref = ref.to(_f32)
+        assert ref.is_cuda and tuple(ref.shape) == (B, Nq, L, 2), 'reference points (B, Nq, L, 2), may be an expanded view'
+        if ref.stride(3) != 1:
+            ref = ref.contiguous()
+        arr, nl = _levels(spatial_shapes)
+        assert nl == L
+        loc = torch.empty(B, Nq, nH, L, P, 2, device=raw.device, dtype=_f32)
+        attw = torch.empty(B, Nq, nH, L, P, device=raw.device, dtype=_f32)
+        es = _es(raw)
+        base = hip.ptr(raw, name='raw')
+        PROFILER.run(f'msda_prep_fwd[B{B} Nq{Nq} {_tag(raw)}]', raw.numel() * es + (loc.numel() + attw.numel()) * 4, lambda: hip.check(
+            hip.lib().ge_msda_prep_fwd(base, ld, base + n_off * es, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+                                       ctypes.cast(arr, ctypes.c_void_p), hip.ptr(loc), hip.ptr(attw), B, Nq, nH, L, P,
+                                       hip.dtype_code(raw), hip.stream()), 'ge_msda_prep_fwd'))
+        ctx.save_for_backward(attw)
+        ctx.meta = (tuple(tuple(int(v) for v in hw) for hw in spatial_shapes), nH, L, P, ld, raw.dtype)
+        return loc, attw
+
+    @staticmethod
+    def backward(ctx, d_loc, d_attw):
+        attw, = ctx.saved_tensors
+        shapes, nH, L, P, ld, dtype = ctx.meta
+        B, Nq = attw.shape[:2]
+        d_loc, d_attw = _c(d_loc.to(_f32)), _c(d_attw.to(_f32))
+        arr, _ = _levels(shapes)
+        d_raw = torch.empty(B, Nq, ld, device=attw.device, dtype=dtype)
+        fused_ref = ctx.needs_input_grad[1] and nH in (1, 2, 4, 8, 16)
+        d_ref = torch.empty(B, Nq, L, 2, device=attw.device, dtype=_f32) if fused_ref else None
+        es = _es(d_raw)
+        base = hip.ptr(d_raw)
+        n_off = nH * L * P * 2
+        PROFILER.run(f'msda_prep_bwd[B{B} Nq{Nq} {_tag(d_raw)}]', d_raw.numel() * es + (d_loc.numel() + 2 * attw.numel()) * 4,
+                     lambda: hip.check(hip.lib().ge_msda_prep_bwd(
+                         hip.ptr(d_loc), hip.ptr(d_attw), hip.ptr(attw), ctypes.cast(arr, ctypes.c_void_p), base, ld,
+                         base + n_off * es, ld, hip.ptr(d_ref), B, Nq, nH, L, P, hip.dtype_code(d_raw), hip.stream()),
+                         'ge_msda_prep_bwd'))
+        if ctx.needs_input_grad[1] and not fused_ref:
+            d_ref = d_loc.sum((2, 4))
+        return d_raw, d_ref, None, None, None, None
+
+
+def msda_prepare(raw, reference_points, spatial_shapes, num_heads, num_levels, num_points):
+    """raw (B,Nq,[nH*L*P*2 offsets | nH*L*P logits]) + reference points (B,Nq,L,2) -> (loc, attw) fp32 for ms_deform_attn."""
+    return _MSDAPrep.apply(raw, reference_points, spatial_shapes, num_heads, num_levels, num_points)
+
+
+# ------------------------------------------------------------------- feature map <-> token sequence
+def _planes(x):
+    """(B,C,H,W) with contiguous (H,W) planes packed over C; the batch stride is free (channel slices of a concat)."""
+    _, C, H, W = x.shape
+    if x.stride(3) == 1 and x.stride(2) == W and x.stride(1) == H * W:
+        return x
+    return x.contiguous()
+
+
+def _rows(t):
+    """(B,N,C) with packed rows; the batch stride is free (token ranges of a longer sequence)."""
+    if t.stride(2) == 1 and t.stride(1) == t.shape[2]:
+        return t
+    return t.contiguous()
+
+
+def _raw_ptr(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name}: gedepth_amd ops run on MI355X only; got a {t.device} tensor')
+    return t.data_ptr()
+
+
+class _TokensFromMap(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, fmap, pos):
+        fmap = _planes(fmap)
+        B, C, H, W = fmap.shape
+        N = H * W
+        if pos is not None:
+            assert not pos.requires_grad and pos.numel() == C * N
+            pos = _c(pos.to(_f32))
+        tok = torch.empty(B, N, C, device=fmap.device, dtype=fmap.dtype)
+        PROFILER.run(f'tokens_from_map[{B}x{C}x{N} {_tag(fmap)}]', 2 * tok.numel() * _es(tok) + (C * N * 4 if pos is not None else 0),
+                     lambda: hip.check(hip.lib().ge_tokens_from_map(
+                         _raw_ptr(fmap, 'map'), fmap.stride(0), hip.ptr(pos), hip.ptr(tok), N * C, B, C, N, 0.0, 0,
+                         hip.dtype_code(fmap), hip.stream()), 'ge_tokens_from_map'))
+        ctx.geom = (B, C, H, W)
+        return tok
+
+    @staticmethod
+    def backward(ctx, d_tok):
+        B, C, H, W = ctx.geom
+        N = H * W
+        d_tok = _rows(d_tok)
+        d_map = torch.empty(B, C, H, W, device=d_tok.device, dtype=d_tok.dtype)
+        PROFILER.run(f'map_from_tokens[{B}x{C}x{N} {_tag(d_tok)}]', 2 * d_map.numel() * _es(d_map), lambda: hip.check(
+            hip.lib().ge_map_from_tokens(_raw_ptr(d_tok, 'd_tok'), d_tok.stride(0), None, 0, hip.ptr(d_map), C * N, B, C, N, 0.0, 0,
+                                         hip.dtype_code(d_tok), hip.stream()), 'ge_map_from_tokens'))
+        return d_map, None
+
+
+def tokens_from_map(fmap, pos=None):
+    """(B,C,H,W) [+ pos (1,C,H,W) fp32] -> (B,H*W,C): ``fmap.flatten(2).transpose(1,2) + pos`` in one transposing pass."""
+    return _TokensFromMap.apply(fmap, pos)
+
+
+class _ConcatTokensMap(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, tok, fmap, identity, tokens_first, p, seed):
+        tok = _rows(tok)
+        B, N, C = tok.shape
+        _, Cm, H, W = fmap.shape
+        assert H * W == N and fmap.shape[0] == B
+        out = torch.empty(B, C + Cm, H, W, device=tok.device, dtype=tok.dtype)
+        t0, m0 = (0, C) if tokens_first else (Cm, 0)
+        res = None
+        if identity is not None:
+            res = _planes(identity.to(tok.dtype))
+            assert tuple(res.shape) == (B, C, H, W)
+        es = _es(tok)
+        PROFILER.run(f'map_from_tokens[{B}x{C}x{N} {_tag(tok)}{" +res" if res is not None else ""}{" drop" if p > 0 else ""}]',
+                     (2 + (res is not None)) * tok.numel() * es, lambda: hip.check(hip.lib().ge_map_from_tokens(
+                         _raw_ptr(tok, 'tokens'), tok.stride(0), None if res is None else _raw_ptr(res, 'identity'),
+                         0 if res is None else res.stride(0), hip.ptr(out) + t0 * N * es, out.stride(0), B, C, N, p, seed,
+                         hip.dtype_code(tok), hip.stream()), 'ge_map_from_tokens'))
+        out[:, m0:m0 + Cm].copy_(fmap)
+        ctx.meta = (B, N, C, Cm, t0, m0, p, seed, identity is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, N, C, Cm, t0, m0, p, seed, has_id = ctx.meta
+        d_out = _c(d_out)
+        es = _es(d_out)
+        d_tok = torch.empty(B, N, C, device=d_out.device, dtype=d_out.dtype)
+        PROFILER.run(f'tokens_from_map[{B}x{C}x{N} {_tag(d_out)}{" drop" if p > 0 else ""}]', 2 * d_tok.numel() * es,
+                     lambda: hip.check(hip.lib().ge_tokens_from_map(
+                         hip.ptr(d_out) + t0 * N * es, d_out.stride(0), None, hip.ptr(d_tok), N * C, B, C, N, p, seed,
+                         hip.dtype_code(d_out), hip.stream()), 'ge_tokens_from_map'))
+        d_slice = d_out[:, t0:t0 + C]
+        return d_tok, d_out[:, m0:m0 + Cm], (d_slice if has_id else None), None, None, None
+
+
+def concat_tokens_map(tokens, fmap, identity=None, tokens_first=True, p_drop=0.0, seed=None):
+    """``torch.cat([to_map(dropout(tokens)) + identity, fmap], 1)`` (or fmap first) with the token part transposed,
+    dropped and added straight into the concat buffer.  tokens (B,H*W,C), fmap (B,Cm,H,W), identity (B,C,H,W)."""
+    p_drop = float(p_drop)
+    if p_drop > 0.0 and seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # host generator: follows torch.manual_seed, no device sync
+    return _ConcatTokensMap.apply(tokens, fmap, identity, bool(tokens_first), p_drop, int(seed or 0))
+
+
 # -------------------------------------------------------------------------------- bilinear
 class _Bilinear(torch.autograd.Function):
 

@@ -99,6 +99,37 @@ int ge_bilinear_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi,
                     int align_corners, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * HAHI neck glue around the deformable attention (necks/hahi.py:303-346 and the mmcv 1.3.13
+ * MultiScaleDeformableAttention.forward it calls).
+ *
+ * ge_msda_prep_fwd: raw outputs of the `sampling_offsets` / `attention_weights` linears -> the fp32 loc / attw tensors
+ *   of ge_msda_fwd in one pass:  loc = ref + off_raw / (W_l, H_l),  attw = softmax_{l,p}(logit_raw).
+ *   off_raw  : rows of B*Nq, row stride off_ld elements, nH*L*P*2 used columns ordered (h,l,p,xy);
+ *   logit_raw: row stride logit_ld, nH*L*P used columns (both may be column ranges of one fused GEMM output);
+ *   ref      : f32 reference points in [0,1], element strides (ref_sb, ref_sq, ref_sl) over (b, q, l), xy adjacent
+ *              (stride 0 = broadcast).  L must be 4, P 4 or 8; row starts 16-byte aligned.
+ * ge_msda_prep_bwd: d_off_raw = d_loc / (W_l, H_l), d_logit_raw = softmax backward; optional d_ref (B*Nq, L, 2) f32
+ *   = sum over heads and points of d_loc (NULL to skip; needs nH in {1,2,4,8,16}).
+ *
+ * ge_tokens_from_map: tok[b,n,c] = (map[b,c,n] + pos[c,n]) * drop(b,n,c)   ("flatten(2).transpose(1,2)" + query_pos add)
+ * ge_map_from_tokens: map[b,c,n] = tok[b,n,c] * drop(b,n,c) + res[b,c,n]   (dropout + identity + "permute(0,2,1).reshape",
+ *   written with batch stride map_bs so it can land inside the torch.cat buffer of hahi.py:333/346).
+ *   Batch strides are in elements; pos (f32, C x N) and res may be NULL; drop() is 1 when p_drop == 0, else a
+ *   counter-based Bernoulli(1 - p_drop) / (1 - p_drop) of (seed, (b*N + n)*C + c): the two entry points with equal
+ *   (seed, p_drop) apply the same mask, which is how each serves as the other's backward.
+ */
+int ge_msda_prep_fwd(const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
+                     long ref_sb, long ref_sq, long ref_sl, const int* spatial_hw, float* loc, float* attw, int B,
+                     int Nq, int nH, int L, int P, int dtype, void* stream);
+int ge_msda_prep_bwd(const float* d_loc, const float* d_attw, const float* attw, const int* spatial_hw, void* d_off_raw,
+                     long off_ld, void* d_logit_raw, long logit_ld, float* d_ref, int B, int Nq, int nH, int L, int P,
+                     int dtype, void* stream);
+int ge_tokens_from_map(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
+                       float p_drop, unsigned long long seed, int dtype, void* stream);
+int ge_map_from_tokens(const void* tok, long tok_bs, const void* res, long res_bs, void* map, long map_bs, int B, int C,
+                       long N, float p_drop, unsigned long long seed, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bias + activation after a bias-free convolution, NCHW, in place: x = act(x + bias[c]) with
  * act = leaky-relu(slope) (slope 0 = ReLU, 1 = identity).  Replaces the broadcast bias add + activation kernels of
  * mmcv ConvModule without norm (decode_heads/densedepth_head.py:14-27) and of the PE-neck convs

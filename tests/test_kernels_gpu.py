@@ -415,6 +415,102 @@ def test_depth_fuse(dev):
     close_scaled(yg.grad, yc.grad, what='d y')
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('P', [8, 4])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_msda_prepare_matches_mmcv_arithmetic(dev, P, dtype):
+    """view -> softmax over L*P -> reference_points + offsets / (W_l, H_l) of mmcv MultiScaleDeformableAttention.forward,
+    forward and backward (incl. the gradient of broadcast reference points), against the ATen sequence."""
+    from gedepth_amd.kernels import msda_prepare
+    B, Nq, nH, L = 2, 37, 8, 4
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    g = gen(11)
+    n_off, n_log = nH * L * P * 2, nH * L * P
+    raw = torch.randn(B, Nq, n_off + n_log, generator=g) * 2
+    ref0 = torch.rand(1, Nq, 2, generator=g)
+    g_loc = torch.randn(B, Nq, nH, L, P, 2, generator=g)
+    g_w = torch.randn(B, Nq, nH, L, P, generator=g)
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    raw = raw.to(td).float()                                                # same stored values on both sides
+    rc, fc = raw.clone().requires_grad_(True), ref0.clone().requires_grad_(True)
+    off = rc[..., :n_off].view(B, Nq, nH, L, P, 2)
+    w_ref = rc[..., n_off:].view(B, Nq, nH, L * P).softmax(-1).view(B, Nq, nH, L, P)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc_ref = fc[:, :, None, :].expand(B, -1, L, 2)[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    (loc_ref * g_loc).sum().add((w_ref * g_w).sum()).backward()
+    rg = raw.to(dev).to(td).requires_grad_(True)
+    fg = ref0.to(dev).requires_grad_(True)
+    loc, w = msda_prepare(rg, fg[:, :, None, :].expand(B, -1, L, 2), shapes, nH, L, P)
+    (loc * g_loc.to(dev)).sum().add((w * g_w.to(dev)).sum()).backward()
+    close(loc, loc_ref, what='loc')
+    close(w, w_ref, what='attw')
+    if dtype == 'f32':
+        close_scaled(rg.grad, rc.grad, what='d raw')
+    else:
+        assert (rg.grad.float().cpu() - rc.grad).abs().max() <= 2 ** -8 * rc.grad.abs().max() + 1e-6
+    close_scaled(fg.grad, fc.grad, what='d reference points')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('geom', [(2, 16, 4, 6), (2, 64, 8, 16), (1, 7, 3, 5), (3, 72, 9, 8)])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_tokens_from_map_and_back(dev, geom, dtype):
+    """flatten(2).transpose(1,2) + pos (hahi.py:303-306) and its inverse with residual + concat (hahi.py:326-333)."""
+    from gedepth_amd.kernels import concat_tokens_map, tokens_from_map
+    B, C, H, W = geom
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = gen(3)
+    fmap = torch.randn(B, C, H, W, generator=g).to(td)
+    pos = torch.randn(1, C, H, W, generator=g)
+    other = torch.randn(B, 5, H, W, generator=g).to(td)
+    go = torch.randn(B, C + 5, H, W, generator=g).to(td)
+    for first in (True, False):
+        fc, oc = fmap.float().clone().requires_grad_(True), other.float().clone().requires_grad_(True)
+        tok_ref = fc.flatten(2).transpose(1, 2) + pos.flatten(2).transpose(1, 2)
+        tok_ref_q = tok_ref.to(td).float()
+        proc = tok_ref * 0.5                                            # stand-in for the attention block
+        m = proc.permute(0, 2, 1).reshape(B, C, H, W) + fc
+        ref = torch.cat([m, oc] if first else [oc, m], 1)
+        ref.backward(go.float())
+        fg, og = fmap.to(dev).requires_grad_(True), other.to(dev).requires_grad_(True)
+        tok = tokens_from_map(fg, pos.to(dev))
+        assert tok.shape == (B, H * W, C) and tok.is_contiguous()
+        out = concat_tokens_map(tok * 0.5, og, identity=fg, tokens_first=first)
+        out.backward(go.to(dev))
+        tol = dict(rtol=2 ** -7, atol=2 ** -7) if dtype == 'bf16' else {}
+        close(tok.float(), tok_ref_q if dtype == 'bf16' else tok_ref, what='tokens', **tol)
+        close(out.float(), ref, what='concat', **tol)
+        close(fg.grad.float(), fc.grad, what='d map', **tol)
+        close(og.grad.float(), oc.grad, what='d other', **tol)
+
+
+@pytest.mark.gpu
+def test_concat_tokens_map_token_slice_and_dropout(dev):
+    """Token ranges of a longer sequence (hahi.py:338-346) and the counter-based dropout: keep rate, 1/(1-p) scaling,
+    identical mask in forward and backward, reproducible for a seed."""
+    from gedepth_amd.kernels import concat_tokens_map
+    B, C, H, W = 2, 64, 16, 24
+    g = gen(4)
+    seq = torch.randn(B, 3 * H * W, C, generator=g).to(dev)
+    ft = torch.randn(B, 8, H, W, generator=g).to(dev)
+    sl = seq[:, H * W:2 * H * W]
+    out = concat_tokens_map(sl, ft, tokens_first=False)
+    assert torch.equal(out[:, 8:], sl.permute(0, 2, 1).reshape(B, C, H, W)) and torch.equal(out[:, :8], ft)
+    p = 0.25
+    tok = torch.ones(B, H * W, C, device=dev, requires_grad=True)
+    o1 = concat_tokens_map(tok, ft, tokens_first=True, p_drop=p, seed=1234)
+    o2 = concat_tokens_map(tok, ft, tokens_first=True, p_drop=p, seed=1234)
+    o3 = concat_tokens_map(tok, ft, tokens_first=True, p_drop=p, seed=1235)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    kept = o1[:, :C] != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+    assert torch.allclose(o1[:, :C][kept], torch.full((), 1 / (1 - p), device=dev))
+    assert abs(kept.float().mean((0, 2, 3)).min().item() - (1 - p)) < 0.06        # no dead channel / striping
+    o1[:, :C].sum().backward()
+    assert torch.equal(tok.grad != 0, kept.flatten(2).transpose(1, 2))
+    assert torch.allclose(tok.grad[tok.grad != 0], torch.full((), 1 / (1 - p), device=dev))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 5, 7, 9), (2, 16, 12, 16), (1, 3, 1, 1)])
 @pytest.mark.parametrize('slope', [1.0, 0.0, 0.01])
 def test_bias_act_fp32(dev, shape, slope):
