@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
+#include <string.h>
+#include <mutex>
+#include <vector>
 
 #define MSDA_MAX_L 8
 struct MsdaLevels { int H[MSDA_MAX_L]; int W[MSDA_MAX_L]; int start[MSDA_MAX_L]; };
@@ -80,15 +83,30 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MB L2.  The sampling kernels read a sliding
+// neighbourhood of `value`, so neighbouring queries should meet in the SAME L2: XCD x works on the x-th contiguous eighth of
+// the (batch, query) range (one image per XCD at 8 images) instead of every eighth workgroup of all of it.
+// rocprofv3 FETCH_SIZE, forward kernel, 8x352x1120: 10.0 GB per launch with the plain mapping.
+#define MSDA_XCDS 8
+__device__ __forceinline__ long msda_xcd_block(unsigned bid, unsigned nblk) {      // nblk is a multiple of MSDA_XCDS
+  return (long)(bid % MSDA_XCDS) * (nblk / MSDA_XCDS) + bid / MSDA_XCDS;
+}
+static inline unsigned msda_grid(long n_items, int per_block) {
+  long b = (n_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  b = (b + MSDA_XCDS - 1) / MSDA_XCDS * MSDA_XCDS;
+  return (unsigned)b;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
                                                   const float* __restrict__ attw, T* __restrict__ out,
                                                   long n_groups, int Nv, int Nq, int nH, int L, int P) {
   constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // lanes per (b,q,head) group: 16 (fp32) / 8 (bf16)
   const int c0 = (threadIdx.x % G) * CPL;
-  const long grp0 = (long)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G);
+  const long grp0 = msda_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x / G) + (threadIdx.x / G);
   const long gstride = (long)gridDim.x * (blockDim.x / G);
-  for (long grp = grp0; grp < n_groups; grp += gstride) {   // grp = (b*Nq + q)*nH + head
+  for (long grp = grp0; grp < n_groups; grp += gstride) {   // grp = (b*Nq + q)*nH + head (one trip: the grid covers all)
     const int head = (int)(grp % nH);
     const long bq = grp / nH;
     const int b = (int)(bq / Nq);
@@ -268,7 +286,7 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
   constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // 16-byte loads: 16 lanes (fp32) / 8 lanes (bf16) per group
   const int sub = threadIdx.x % G;
   const int c0 = sub * CPL;
-  const long grp0 = (long)blockIdx.x * (blockDim.x / G) + (threadIdx.x / G);
+  const long grp0 = msda_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x / G) + (threadIdx.x / G);
   const long gstride = (long)gridDim.x * (blockDim.x / G);
   const long iters = (n_groups + gstride - 1) / gstride;          // wave-uniform trip count: the shuffles need all lanes
   const int LP = L * P;
@@ -393,7 +411,7 @@ typedef float f32x32_t __attribute__((ext_vector_type(32)));
 struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; };     // tiles of level l: [first_tile[l], first_tile[l+1])
 
 struct MsdaWs {            // device workspace carved by the host wrapper
-  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int2* entries;   // ctrl[0] = total chunks, ctrl[1] = next
+  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int2* entries;   // ctrl[0] = total chunks, ctrl[2+x] = next chunk of XCD x's share
 };
 
 // Binning = a counting sort with workgroup-private LDS histograms (global integer atomics cost one L2 request per
@@ -405,12 +423,14 @@ struct MsdaWs {            // device workspace carved by the host wrapper
 #define MSDA_SEG 65536
 template <bool FILL>
 __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
-                                                   const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P) {
+                                                   const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P, int nseg, int B) {
   extern __shared__ int hist[];                          // [nH * ntiles]
   const int ntiles = bins.first_tile[L];
   const int nloc = nH * ntiles;
   const int LP = L * P;
-  const int b = blockIdx.y, seg = blockIdx.x, nseg = gridDim.x;
+  const long vb = msda_xcd_block(blockIdx.x, gridDim.x);        // neighbouring segments (same value tiles) share an XCD
+  if (vb >= (long)nseg * B) return;
+  const int b = (int)(vb / nseg), seg = (int)(vb - (long)b * nseg);
   const long npts_b = (long)Nq * nH * LP;
   int* gh = ws.seg_hist + ((long)b * nseg + seg) * nloc;
   for (int i = threadIdx.x; i < nloc; i += 256) hist[i] = FILL ? gh[i] : 0;
@@ -493,7 +513,8 @@ __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
     if (threadIdx.x == 1023) { carry_off += s_off[1023]; carry_chk += s_chk[1023]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { ws.chunk_first[nbins] = carry_chk; ws.ctrl[0] = carry_chk; ws.ctrl[1] = 0; }
+  if (threadIdx.x == 0) { ws.chunk_first[nbins] = carry_chk; ws.ctrl[0] = carry_chk; }
+  if (threadIdx.x >= 1 && threadIdx.x < 2 + MSDA_XCDS) ws.ctrl[threadIdx.x] = 0;      // per-XCD work cursors
 }
 
 template <typename T>
@@ -503,11 +524,22 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
   const int lane = threadIdx.x & 63;
   const int ntiles = bins.first_tile[L];
   const int total = ws.ctrl[0];
+  // chunks are ordered by (image, head, tile): XCD x drains the x-th eighth of the list, so that neighbouring tiles — whose
+  // entries point at the same gradient rows — meet in one L2; a wave that runs dry helps the next partition
+  const int part0 = blockIdx.x % MSDA_XCDS;
+  int probe = 0;
   for (;;) {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(&ws.ctrl[1], 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= total) break;
+    int item = -1;
+    while (probe < MSDA_XCDS) {
+      const int part = (part0 + probe) % MSDA_XCDS;
+      const int p_lo = (int)((long)total * part / MSDA_XCDS), p_hi = (int)((long)total * (part + 1) / MSDA_XCDS);
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&ws.ctrl[2 + part], 1);
+      k = __builtin_amdgcn_readfirstlane(k);
+      if (p_lo + k < p_hi) { item = p_lo + k; break; }
+      ++probe;
+    }
+    if (item < 0) break;
     int lo = 0, hi = nbins;                               // largest bin with chunk_first[bin] <= item
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_first[mid] <= item) lo = mid; else hi = mid; }
     const int bin = lo;
@@ -583,7 +615,7 @@ static size_t msda_ws_layout(int nbins, long seg_hist_ints, long max_entries, ch
   size_t off = 0;
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_cnt = carve((size_t)nbins * 4), o_chk = carve((size_t)(nbins + 1) * 4);
-  const size_t o_off = carve((size_t)(nbins + 1) * 8), o_ctrl = carve(16), o_sh = carve((size_t)seg_hist_ints * 4);
+  const size_t o_off = carve((size_t)(nbins + 1) * 8), o_ctrl = carve(64), o_sh = carve((size_t)seg_hist_ints * 4);
   const size_t o_ent = carve((size_t)max_entries * 8);
   if (ws) {
     ws->cnt = (int*)(base + o_cnt); ws->chunk_first = (int*)(base + o_chk); ws->offset = (long*)(base + o_off);
@@ -630,7 +662,8 @@ extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const float
   if (e) return e;
   const long n_groups = (long)B * Nq * nH;
   if (n_groups == 0) return GE_OK;
-  const unsigned blocks = ge_blocks(n_groups, dtype == GE_BF16 ? 32 : 16, 1 << 22);
+  if ((n_groups + 15) / 16 > (1L << 30)) return GE_ERR_UNSUPPORTED;
+  const unsigned blocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
   if (dtype == GE_F32)
     msda_fwd_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)value, lv, loc, attw, (float*)out, n_groups, Nv, Nq, nH, L, P);
   else if (dtype == GE_BF16)
@@ -649,6 +682,60 @@ extern "C" size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, in
   const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
   if (!pl.ok) return 0;
   return msda_ws_layout(pl.nbins, (long)B * pl.nseg * pl.nloc, pl.max_entries, nullptr, nullptr);
+}
+
+// ---- optional per-kernel timing of the composite backward: a measurement aid for bench.py (its roofline object needs
+// the duration of ONE kernel, and HIP events recorded by the caller can only bracket the whole entry point).  Off by
+// default; when off the entry point records nothing and never synchronises.
+#define MSDA_NSTAGE 5
+static const char* const kMsdaStage[MSDA_NSTAGE] = {"msda_bwd_lw_k", "msda_hist_k<false>", "msda_scan_k+msda_segscan_k",
+                                                    "msda_hist_k<true>", "msda_drain_k"};
+struct MsdaStageRec { int stage; hipEvent_t a, b; };
+static std::mutex g_msda_mu;
+static bool g_msda_timing = false;
+static std::vector<MsdaStageRec> g_msda_pending;
+static double g_msda_ms[MSDA_NSTAGE];
+static long g_msda_n[MSDA_NSTAGE];
+
+static void msda_mark(hipEvent_t* ev, int i, hipStream_t s) {
+  if (!ev) return;
+  (void)hipEventCreate(&ev[i]);
+  (void)hipEventRecord(ev[i], s);
+}
+static void msda_flush_locked() {
+  for (auto& r : g_msda_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_msda_ms[r.stage] += ms;
+      g_msda_n[r.stage] += 1;
+    }
+  }
+  // every event is shared by two records (end of one stage, start of the next): destroy each once
+  std::vector<hipEvent_t> seen;
+  for (auto& r : g_msda_pending)
+    for (hipEvent_t e : {r.a, r.b}) {
+      bool dup = false;
+      for (hipEvent_t x : seen) dup |= (x == e);
+      if (!dup) { seen.push_back(e); (void)hipEventDestroy(e); }
+    }
+  g_msda_pending.clear();
+}
+
+extern "C" int ge_msda_bwd_timing(int enable) {
+  std::lock_guard<std::mutex> lk(g_msda_mu);
+  msda_flush_locked();
+  for (int i = 0; i < MSDA_NSTAGE; ++i) { g_msda_ms[i] = 0.0; g_msda_n[i] = 0; }
+  g_msda_timing = enable != 0;
+  return GE_OK;
+}
+extern "C" int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launches, char* name, int name_cap) {
+  if (stage < 0 || stage >= MSDA_NSTAGE || !total_ms || !launches) return GE_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(g_msda_mu);
+  msda_flush_locked();
+  *total_ms = g_msda_ms[stage];
+  *launches = g_msda_n[stage];
+  if (name && name_cap > 0) { strncpy(name, kMsdaStage[stage], (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+  return GE_OK;
 }
 
 extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out,
@@ -683,34 +770,47 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   }
 #undef MSDA_BWD_P
 #undef MSDA_BWD
+  hipEvent_t evs[MSDA_NSTAGE + 1];
+  hipEvent_t* ev = nullptr;
+  { std::lock_guard<std::mutex> lk(g_msda_mu); if (g_msda_timing) ev = evs; }
+  msda_mark(ev, 0, s);
   {
-    const unsigned lblocks = ge_blocks(n_groups, dtype == GE_BF16 ? 32 : 16, 256 * 64);
+    const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);   // one trip per workgroup, in query order
     if (dtype == GE_F32)
       msda_bwd_lw_k<float><<<lblocks, 256, 0, s>>>((const float*)value, lv, loc, attw, (const float*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
     else
       msda_bwd_lw_k<bf16_t><<<lblocks, 256, 0, s>>>((const bf16_t*)value, lv, loc, attw, (const bf16_t*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
   }
   GE_LAUNCH_CHECK();
+  msda_mark(ev, 1, s);
   const int nbins = pl.nbins;
   MsdaWs ws;
   msda_ws_layout(nbins, seg_ints, pl.max_entries, (char*)workspace, &ws);
   hipError_t he = hipMemsetAsync(ws.cnt, 0, (size_t)nbins * 4, s);
   if (he != hipSuccess) return (int)he;
-  dim3 hgrid((unsigned)pl.nseg, (unsigned)B);
+  const unsigned hgrid = msda_grid((long)pl.nseg * B, 1);
   const size_t hsmem = (size_t)pl.nloc * 4;
-  msda_hist_k<false><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P);
+  msda_hist_k<false><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B);
   GE_LAUNCH_CHECK();
+  msda_mark(ev, 2, s);
   msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
   GE_LAUNCH_CHECK();
   msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.nloc, pl.nseg, B);
   GE_LAUNCH_CHECK();
-  msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P);
+  msda_mark(ev, 3, s);
+  msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B);
   GE_LAUNCH_CHECK();
+  msda_mark(ev, 4, s);
   if (dtype == GE_F32)
     msda_drain_k<float><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
   else
     msda_drain_k<bf16_t><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
   GE_LAUNCH_CHECK();
+  msda_mark(ev, 5, s);
+  if (ev) {
+    std::lock_guard<std::mutex> lk(g_msda_mu);
+    for (int i = 0; i < MSDA_NSTAGE; ++i) g_msda_pending.push_back(MsdaStageRec{i, ev[i], ev[i + 1]});
+  }
   return GE_OK;
 }
 

@@ -25,6 +25,8 @@ SIGNATURES = {
     'ge_msda_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_workspace': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_bwd_timing': (_i, [_i]),
+    'ge_msda_bwd_timing_read': (_i, [_i, _vp, _vp, _vp, _i]),
     'ge_msda_prep_fwd': (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_prep_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_tokens_from_map': (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _l, _f, _u64, _i, _vp]),

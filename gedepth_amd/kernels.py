@@ -20,13 +20,31 @@ class _Profiler:
     """Per-kernel HIP-event timing on the launch stream (bench.py's roofline object).  Off by default."""
 
     def __init__(self):
-        self.on, self.records = False, {}
+        self.on, self.records, self.stage_bytes = False, {}, {}
 
     def enable(self):
-        self.on, self.records = True, {}
+        self.on, self.records, self.stage_bytes = True, {}, {}
+        hip.lib().ge_msda_bwd_timing(1)
 
     def disable(self):
         self.on = False
+
+    def add_stage_bytes(self, per_stage):
+        """algorithmic bytes of one composite ge_msda_bwd call, per kernel (stage order of ge_msda_bwd_timing_read)"""
+        for i, b in enumerate(per_stage):
+            self.stage_bytes[i] = self.stage_bytes.get(i, 0) + int(b)
+
+    def msda_bwd_stages(self):
+        """Per-kernel records of the composite MSDA backward, timed by HIP events inside the library."""
+        out = []
+        total, n, name = ctypes.c_double(), ctypes.c_long(), ctypes.create_string_buffer(64)
+        for i in range(5):
+            hip.check(hip.lib().ge_msda_bwd_timing_read(i, ctypes.addressof(total), ctypes.addressof(n),
+                                                        ctypes.addressof(name), 64), 'ge_msda_bwd_timing_read')
+            if n.value:
+                out.append(dict(name=name.value.decode(), launches=n.value, avg_us=1e3 * total.value / n.value,
+                                total_ms=total.value, bytes_per_launch=self.stage_bytes.get(i, 0) / n.value))
+        return out
 
     def run(self, name, nbytes, call):
         if not self.on:
@@ -152,6 +170,10 @@ class _MSDeformAttn(torch.autograd.Function):
         shapes_p = ctypes.cast(arr, ctypes.c_void_p)
         ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P)) if MSDA_BINNED_BACKWARD else 0
         ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8) if ws_bytes else None
+        if PROFILER.on and ws_bytes:
+            lw_b = value.numel() * _es(value) + 2 * (loc.numel() + attw.numel()) * 4 + d_out.numel() * _es(d_out)
+            la_b = (loc.numel() + attw.numel()) * 4
+            PROFILER.add_stage_bytes((lw_b, la_b, 0, la_b, d_out.numel() * _es(d_out) + d_value.numel() * 4))
         PROFILER.run(f'msda_bwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}{" binned" if ws_bytes else ""}]', nbytes, lambda: hip.check(
             lib.ge_msda_bwd(hip.ptr(value), shapes_p, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
                             hip.ptr(d_value), hip.ptr(d_loc), hip.ptr(d_attw), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P,

@@ -1,0 +1,45 @@
+"""Library-kernel selection caches for the parts of the step that stay in rocBLAS / hipBLASLt / MIOpen.
+
+The Linear layers of the Swin encoder and of the HAHI attention run as library GEMMs (plain GEMMs are not worth a
+hand-written kernel).  hipBLASLt's default heuristic picks poor macro-tiles for the tall-skinny shapes of this
+model (M = 8 x 24640 ... 8 x 98560 tokens, K and N of 96 ... 768): PyTorch's TunableOp times the candidate solutions
+once and records the winner per shape.  The winners for the BASELINE workloads on gfx950 are committed in
+``gedepth_amd/tuning/tunableop_gfx950.csv`` and only *looked up* at run time (no tuning, no start-up cost); shapes that
+are not in the file use the library default.  ``tools/tune_gemms.py`` regenerates the file.
+"""
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GEMM_TABLE = os.path.join(os.path.dirname(_HERE), 'tuning', 'tunableop_gfx950.csv')
+MIOPEN_DB = os.path.join(os.path.dirname(_HERE), 'tuning', 'miopen')
+
+
+def use_tuned_gemms(mode='load', path=GEMM_TABLE):
+    """mode: 'off' | 'load' (look up the committed table) | 'tune' (time unseen shapes and append them on exit)."""
+    import torch.cuda.tunable as tunable
+    if mode == 'off':
+        tunable.enable(False)
+        return False
+    if mode not in ('load', 'tune'):
+        raise ValueError(f'gemm tuning mode {mode!r}')
+    tunable.enable(True)
+    tunable.tuning_enable(mode == 'tune')
+    tunable.set_filename(path, insert_device_ordinal=False)
+    if os.path.isfile(path):
+        tunable.read_file(path)
+    elif mode == 'load':
+        tunable.enable(False)
+        return False
+    return True
+
+
+def use_miopen_find_db(path=MIOPEN_DB):
+    """Point MIOpen's user find-db at the committed directory (must run before the first convolution).  With the db in
+    place ``torch.backends.cudnn.benchmark = True`` resolves every convolution of the BASELINE workloads from the db
+    instead of timing the solvers for minutes on a fresh machine."""
+    if os.path.isdir(path) and os.listdir(path):
+        os.environ.setdefault('MIOPEN_USER_DB_PATH', path)
+        return True
+    return False

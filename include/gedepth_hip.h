@@ -98,6 +98,14 @@ int ge_bilinear_fwd(const void* in, void* out, int N, int C, int Hi, int Wi, int
 int ge_bilinear_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi, int Ho, int Wo,
                     int align_corners, int dtype, void* stream);
 
+/* Measurement aid (bench.py): per-kernel durations of the composite ge_msda_bwd.  ge_msda_bwd_timing(1) resets the
+ * counters and makes every following workspace-backed ge_msda_bwd record HIP events between its kernels on the launch
+ * stream; ge_msda_bwd_timing_read(stage, ...) waits for the recorded events and returns the accumulated milliseconds,
+ * the launch count and the kernel name of stage 0..4 (lw, count, scan, fill, drain).  Off by default: the entry point
+ * then records nothing and never synchronises. */
+int ge_msda_bwd_timing(int enable);
+int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launches, char* name, int name_cap);
+
 /* ---------------------------------------------------------------------------------------------
  * HAHI neck glue around the deformable attention (necks/hahi.py:303-346 and the mmcv 1.3.13
  * MultiScaleDeformableAttention.forward it calls).

@@ -40,6 +40,8 @@ def parse_args():
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic KITTI-shaped samples')
     p.add_argument('--fp32', action='store_true', help='disable bf16 autocast')
+    p.add_argument('--gemm-tuning', default='load', choices=['off', 'load', 'tune'],
+                   help='hipBLASLt/rocBLAS solution table for the Linear layers (gedepth_amd/mmrt/tuning.py)')
     return p.parse_args()
 
 
@@ -59,6 +61,8 @@ def main():
     rank, local, world = init_dist(cfg.get('dist_params', {}).get('backend', 'nccl')) if distributed else (0, 0, 1)
     if not distributed:
         torch.cuda.set_device(0)
+    from gedepth_amd.mmrt.tuning import use_tuned_gemms
+    use_tuned_gemms(args.gemm_tuning)
     os.makedirs(cfg.work_dir, exist_ok=True)
     if rank == 0:
         cfg.dump(osp.join(cfg.work_dir, osp.basename(args.config)))
