@@ -37,8 +37,9 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-tuning', default='load', choices=['off', 'load', 'tune'],
                     help='hipBLASLt/rocBLAS solution table for the Linear layers (gedepth_amd/mmrt/tuning.py)')
-    ap.add_argument('--cudnn-benchmark', type=int, default=0,
-                    help='1 = MIOpen exhaustive find (configs: cudnn_benchmark=True): ~3 %% faster steps, but minutes of tuning on a fresh box')
+    ap.add_argument('--cudnn-benchmark', type=int, default=-1,
+                    help='MIOpen find mode (configs: cudnn_benchmark=True): +6 %% step rate; -1 = on when the committed find-db '
+                         '(gedepth_amd/tuning/miopen) is usable, else off (finding from scratch takes ~5 min on a fresh box)')
     return ap.parse_args()
 
 
@@ -97,8 +98,9 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark)
-    from gedepth_amd.mmrt.tuning import use_tuned_gemms
+    from gedepth_amd.mmrt.tuning import use_miopen_find_db, use_tuned_gemms
+    have_db = use_miopen_find_db() if args.cudnn_benchmark != 0 else False
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark == 1 or (args.cudnn_benchmark == -1 and have_db))
     use_tuned_gemms(args.gemm_tuning)
 
     from gedepth_amd import hip, kernels
@@ -180,7 +182,7 @@ def main():
             res['kernels'] = [{'name': r['name'], 'launches': r['launches'], 'avg_us': round(r['avg_us'], 2),
                                'GBps': round(r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9, 1),
                                'share_of_step': round(r['total_ms'] / (1e3 * elapsed), 4)} for r in
-                              sorted(prof + stages, key=lambda r: -r['total_ms'])]
+                              sorted(prof + stages, key=lambda r: -r['total_ms'])[:24]]
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.config, args.height, args.width)
         print(json.dumps(res), flush=True)

@@ -408,6 +408,7 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
 #define MSDA_CHUNK 4096
 #define MSDA_DRAIN_U 32
 typedef float f32x32_t __attribute__((ext_vector_type(32)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; };     // tiles of level l: [first_tile[l], first_tile[l+1])
 
 struct MsdaWs {            // device workspace carved by the host wrapper
@@ -517,11 +518,33 @@ __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
   if (threadIdx.x >= 1 && threadIdx.x < 2 + MSDA_XCDS) ws.ctrl[threadIdx.x] = 0;      // per-XCD work cursors
 }
 
+// drain: a wave owns one chunk (<= MSDA_CHUNK entries of one bin) and accumulates its tile in 32 VGPRs per lane
+// (lane == channel).  Measured on the first version, which consumed entries in arrival order with `acc[pos] += g * coef`
+// and pos as a dynamic register index: that costs 6 VALU + 5 SALU instructions per entry (v_readlane x2, index on/off,
+// v_mov / v_fmac / v_mov) and the kernel was VALU-issue bound (12.5 ms for the 8 x 352 x 1120 cross-attention).
+// Now each sub-chunk of MSDA_SUB entries is first counting-sorted BY POSITION in LDS — lane-parallel, ~0.2 instructions
+// per entry — and consumed run by run into ONE statically addressed accumulator: 3 VALU per entry (bf16 -> f32 shift,
+// v_readlane of the coefficient, v_fmac) and one LDS read (the lane's channel of the staged gradient row), all 32 reads of a
+// block issued before the first use; the dynamic register index is paid once per position run.  Gradient rows are fetched 16 bytes per lane (8 rows of 128 B per instruction for
+// bf16), double-buffered through a wave-private LDS stage.
+#define MSDA_SUB 1024
 template <typename T>
 __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins, MsdaWs ws, const T* __restrict__ gout,
                                                     float* __restrict__ d_value, int nbins, int Nv, int Nq, int nH, int L) {
+  constexpr int CPLr = 16 / (int)sizeof(T);            // channels per lane in a 16-byte gather
+  constexpr int LPR = 64 / CPLr;                       // lanes per gradient row: 8 (bf16) / 16 (fp32)
+  constexpr int RPI = 64 / LPR;                        // rows per gather instruction: 8 / 4
+  constexpr int NR = 32 / RPI;                         // gather instructions per 32-row block: 4 / 8
   __shared__ __attribute__((aligned(16))) T stage_all[4 * 2 * 32 * 64];   // per wave: 2 buffers x 32 rows x 64 channels
-  const int lane = threadIdx.x & 63;
+  __shared__ int s_q_all[4 * MSDA_SUB];
+  __shared__ float s_cf_all[4 * MSDA_SUB];
+  __shared__ int s_start_all[4 * 40];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  T* stage = stage_all + (size_t)wv * (2 * 32 * 64);
+  int* s_q = s_q_all + wv * MSDA_SUB;
+  float* s_cf = s_cf_all + wv * MSDA_SUB;
+  int* s_start = s_start_all + wv * 40;                // [0..31] run starts, [32] = n, [33] = never reached
+  const int gi = lane / LPR, subc = (lane % LPR) * CPLr;
   const int ntiles = bins.first_tile[L];
   const int total = ws.ctrl[0];
   // chunks are ordered by (image, head, tile): XCD x drains the x-th eighth of the list, so that neighbouring tiles — whose
@@ -557,46 +580,91 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
     const long rowbase = (long)b * Nq * nH + head;
 
     f32x32_t a0 = 0.f;
-    // Gather + accumulate, software-pipelined in half-blocks of 32 entries.
-    //  gather : a vector-memory instruction costs ~25-33 cycles per CU whatever it fetches, so rows are fetched FOUR per
-    //           instruction (16 lanes x 4 channels each, like the forward kernel) and parked in a wave-private LDS stage;
-    //  consume: lane == channel again: one ds_read per tap (cheap) and `acc[pos] += g * coef` with pos as a wave-uniform
-    //           dynamic register index.  Half-block n+1 is in flight while half-block n is consumed.
-    T* stage = stage_all + (size_t)(threadIdx.x >> 6) * (2 * 32 * 64);
-    const int gi = lane >> 4, sub4 = (lane & 15) * 4;
-    typename Vec4Raw<T>::type R[8];
-    int2 mine = make_int2(0, 0), nxt = make_int2(0, 0);     // coef 0: harmless padding entry (query 0, position 0)
-    if (e_lo + lane < e_hi) mine = ent[e_lo + lane];
-    // MINE/HB: entries [HB*32, HB*32+32) of the 64-entry register block MINE
-#define MSDA_GATHER(MINE, HB)                                                                              \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
-    const int key = __shfl(MINE.x, (HB) * 32 + 4 * i + gi, 64);                                            \
-    R[i] = Vec4Raw<T>::ld(gout + (rowbase + (long)(key >> 8) * nH) * 64 + sub4);                           \
+    for (int s_lo = e_lo; s_lo < e_hi; s_lo += MSDA_SUB) {
+      const int n = min(MSDA_SUB, e_hi - s_lo);
+      // ---- counting sort of the sub-chunk by position (one entry per lane per step; LDS integer atomics are cheap)
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 34) s_start[lane] = 0;
+      __builtin_amdgcn_wave_barrier();
+      int2 E[MSDA_SUB / 64];
+      int rank[MSDA_SUB / 64];
+#pragma unroll
+      for (int i = 0; i < MSDA_SUB / 64; ++i) {
+        const int idx = i * 64 + lane;
+        E[i] = make_int2(0, 0);
+        rank[i] = 0;
+        if (idx < n) {
+          E[i] = ent[s_lo + idx];
+          rank[i] = atomicAdd(&s_start[E[i].x & 31], 1);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int c = lane < 32 ? s_start[lane] : 0;
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(inc, d, 64); if ((lane & 31) >= d) inc += t; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) s_start[lane] = inc - c;
+        if (lane == 32) { s_start[32] = n; s_start[33] = 0x7fffffff; }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < MSDA_SUB / 64; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < n) {
+          const int slot = s_start[E[i].x & 31] + rank[i];
+          s_q[slot] = E[i].x >> 8;
+          s_cf[slot] = __int_as_float(E[i].y);
+        }
+      }
+      const int nb = (n + 31) >> 5;                        // 32-entry blocks; pad the last one with coef 0 / query 0
+      if (n + lane < nb * 32 && lane < 32) { s_q[n + lane] = 0; s_cf[n + lane] = 0.f; }
+      __builtin_amdgcn_wave_barrier();
+
+      // ---- gather (double-buffered) + run-wise accumulation
+      u32x4_t R[NR];                                       // (HIP's uint4 struct kept this array in scratch)
+#define MSDA_GATHER(BLK)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                         \
+    const int q = s_q[(BLK) * 32 + i * RPI + gi];                                                          \
+    R[i] = *(const u32x4_t*)(gout + (rowbase + (long)q * nH) * 64 + subc);                                   \
   }
 #define MSDA_PARK(BUF)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 8; ++i) Vec4Raw<T>::st(stage + ((BUF) * 32 + 4 * i + gi) * 64 + sub4, R[i]);
-#define MSDA_CONSUME(MINE, HB, BUF)                                                                        \
-  _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                         \
-    const int key = __builtin_amdgcn_readlane(MINE.x, (HB) * 32 + k);                                      \
-    const float cf = __int_as_float(__builtin_amdgcn_readlane(MINE.y, (HB) * 32 + k));                     \
-    const float gv = cf * Ld1<T>::ld(stage + ((BUF) * 32 + k) * 64 + lane);                                \
-    a0[key & 31] += gv;   /* (two blocks + if/else made the compiler copy all 32 registers per tap) */      \
-  }
-    if (e_lo < e_hi) { MSDA_GATHER(mine, 0) MSDA_PARK(0) }
-    for (int e0 = e_lo; e0 < e_hi; e0 += 64) {
-      nxt = make_int2(0, 0);
-      if (e0 + 64 + lane < e_hi) nxt = ent[e0 + 64 + lane];
-      MSDA_GATHER(mine, 1)                      // second half of this block in flight ...
-      MSDA_CONSUME(mine, 0, 0)                  // ... while the first half is consumed
-      MSDA_PARK(1)
-      if (e0 + 64 < e_hi) { MSDA_GATHER(nxt, 0) }
-      MSDA_CONSUME(mine, 1, 1)
-      if (e0 + 64 < e_hi) { MSDA_PARK(0) }
-      mine = nxt;
-    }
+  _Pragma("unroll") for (int i = 0; i < NR; ++i) *(u32x4_t*)(stage + ((BUF) * 32 + i * RPI + gi) * 64 + subc) = R[i];
+      int pos = 0;
+      int run_end = __builtin_amdgcn_readfirstlane(s_start[1]);
+      float acc = 0.f;
+      MSDA_GATHER(0)
+      MSDA_PARK(0)
+      for (int blk = 0; blk < nb; ++blk) {
+        const int buf = blk & 1;
+        if (blk + 1 < nb) { MSDA_GATHER(blk + 1) }           // in flight while this block is consumed
+        const T* sp = stage + buf * 32 * 64 + lane;
+        const int i0 = blk * 32;
+        // all 32 gradient values and the 32 coefficients (one per lane) are fetched up front: the run-boundary branches
+        // below would otherwise serialise every entry on an LDS round trip
+        float gr[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) gr[k] = Ld1<T>::ld(sp + k * 64);
+        const float cfl = s_cf[i0 + (lane & 31)];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          if (__builtin_expect(i0 + k == run_end, 0)) {      // wave-uniform and rare: keep the hot path fall-through
+            do {                                             // close the run of `pos` (and any empty runs behind it)
+              a0[pos & 31] += pos < 32 ? acc : 0.f;          // (a branch here makes the compiler copy all 32 registers)
+              acc = 0.f;
+              ++pos;
+              run_end = __builtin_amdgcn_readfirstlane(s_start[min(pos + 1, 33)]);
+            } while (i0 + k == run_end);
+          }
+          acc += readlane_f(cfl, k) * gr[k];
+        }
+        if (blk + 1 < nb) { MSDA_PARK(buf ^ 1) }
+      }
+      a0[pos & 31] += pos < 32 ? acc : 0.f;
 #undef MSDA_GATHER
 #undef MSDA_PARK
-#undef MSDA_CONSUME
+    }
     float* dst = d_value + (((long)b * Nv + lv.start[l] + tile_lo) * nH + head) * 64 + lane;
     const long pstride = (long)nH * 64;
 #define MSDA_FLUSH(vec, base)                                                       \
@@ -802,9 +870,9 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   GE_LAUNCH_CHECK();
   msda_mark(ev, 4, s);
   if (dtype == GE_F32)
-    msda_drain_k<float><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
+    msda_drain_k<float><<<256 * 2, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
   else
-    msda_drain_k<bf16_t><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
+    msda_drain_k<bf16_t><<<256 * 2, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 5, s);
   if (ev) {

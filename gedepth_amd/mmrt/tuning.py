@@ -9,8 +9,6 @@ are not in the file use the library default.  ``tools/tune_gemms.py`` regenerate
 """
 import os
 
-import torch
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 GEMM_TABLE = os.path.join(os.path.dirname(_HERE), 'tuning', 'tunableop_gfx950.csv')
 MIOPEN_DB = os.path.join(os.path.dirname(_HERE), 'tuning', 'miopen')
@@ -36,10 +34,21 @@ def use_tuned_gemms(mode='load', path=GEMM_TABLE):
 
 
 def use_miopen_find_db(path=MIOPEN_DB):
-    """Point MIOpen's user find-db at the committed directory (must run before the first convolution).  With the db in
-    place ``torch.backends.cudnn.benchmark = True`` resolves every convolution of the BASELINE workloads from the db
-    instead of timing the solvers for minutes on a fresh machine."""
-    if os.path.isdir(path) and os.listdir(path):
-        os.environ.setdefault('MIOPEN_USER_DB_PATH', path)
-        return True
-    return False
+    """Seed MIOpen's user find-db with the committed one (call before the first convolution, i.e. before MIOpen creates
+    its handle).  With the db in place ``torch.backends.cudnn.benchmark = True`` resolves every convolution of the BASELINE
+    workloads from the db (+6 % step rate) instead of timing all solvers for ~5 minutes on a fresh machine.  The db is
+    copied to a scratch directory because MIOpen appends to it while running."""
+    import shutil
+    import tempfile
+    if os.environ.get('MIOPEN_USER_DB_PATH'):
+        return True                                    # the user manages the db
+    files = [f for f in (os.listdir(path) if os.path.isdir(path) else []) if f.endswith('db.txt')]
+    if not files:
+        return False
+    dst = os.path.join(tempfile.gettempdir(), f'gedepth_amd_miopen_db_{os.getuid()}_{os.environ.get("LOCAL_RANK", "0")}')
+    os.makedirs(dst, exist_ok=True)
+    for f in files:
+        if not os.path.isfile(os.path.join(dst, f)):
+            shutil.copy(os.path.join(path, f), os.path.join(dst, f))
+    os.environ['MIOPEN_USER_DB_PATH'] = dst
+    return True

@@ -61,8 +61,11 @@ def main():
     rank, local, world = init_dist(cfg.get('dist_params', {}).get('backend', 'nccl')) if distributed else (0, 0, 1)
     if not distributed:
         torch.cuda.set_device(0)
-    from gedepth_amd.mmrt.tuning import use_tuned_gemms
+    from gedepth_amd.mmrt.tuning import use_miopen_find_db, use_tuned_gemms
     use_tuned_gemms(args.gemm_tuning)
+    if cfg.get('cudnn_benchmark', False):
+        use_miopen_find_db()
+        torch.backends.cudnn.benchmark = True
     os.makedirs(cfg.work_dir, exist_ok=True)
     if rank == 0:
         cfg.dump(osp.join(cfg.work_dir, osp.basename(args.config)))
