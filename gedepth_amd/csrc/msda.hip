@@ -389,30 +389,31 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// d_value without per-channel atomics: bin the taps by value tile, then accumulate each tile in REGISTERS.
+// d_value without per-channel atomics: bin the sampling points by value tile, then accumulate each tile in REGISTERS.
 //
 // Measured on MI355X (scratch/ubench): the L2 executes fp32 atomics at ~1 dword/clock/channel (5.0 G 256-byte bursts/s
 // chip-wide, independent of footprint and scope) and LDS fp32 atomics are slower still (ds_add_f32: ~170 cycles per
-// wave-instruction per CU).  The direct scatter needs 64 dword atomics per tap, which pins the cross-attention of 8
-// images at ~140 ms.  Binning needs ONE integer atomic per tap:
-//   count : one sampling point per lane (perfectly coalesced loc / attw), 4 taps -> atomicAdd(count[bin], 1)
-//   scan  : exclusive prefix of the counts -> bin offsets, and the list of 4096-entry chunks
-//   fill  : same traversal, slot = offset[bin] + atomicAdd(cursor[bin], 1); entries[slot] = {query<<8 | pos, coef}
-//   drain : persistent waves pull chunks from a device-side work counter; lane == channel; entries are read
-//           64 at a time (coalesced) and broadcast with v_readlane; per tap ONE coalesced read of the query's gradient
-//           row (16 in flight) and `acc[pos] += g*coef` with pos as a wave-uniform dynamic register index
-//           (s_set_gpr_idx: the 64-position tile lives in 64 VGPRs per lane — no LDS, no atomics); a finished
-//           chunk is added to d_value with 128 atomic bursts, i.e. ~3 % of the original atomic traffic.
-// A bin = MSDA_TILE consecutive positions of one (batch, head, level).
-#define MSDA_TILE 32           // positions per bin = one 32-register accumulator block per lane (dynamic index: 11 instr/tap)
+// wave-instruction per CU).  The direct scatter needs 4 x 64 dword atomics per sampling point, which pins the
+// cross-attention of 8 images at ~140 ms.  Binning needs ONE integer (LDS) atomic per record:
+//   count : one sampling point per lane (perfectly coalesced loc / attw) -> LDS histogram of the tiles it touches
+//   scan  : exclusive prefix of the counts -> bin offsets, and the list of 4096-record chunks
+//   fill  : same traversal, slot from the LDS cursor; records[slot] = {query, corner position in the tile, w, ax, ay}
+//   drain : persistent waves, one chunk each; see msda_drain_k.
+// A bin = one 8 x 4 TILE of positions of one (batch, head, level).  The four bilinear corners of a sampling point share
+// ONE gradient row, and with a 2-D tile they share one tile 71 % of the time: a record is a (point, tile) pair — 1.41 per
+// point on average instead of 4 (point, corner) entries — so the drain gathers 2.8x fewer gradient rows and the record
+// list is 22.6 instead of 32 bytes per point.
+#define MSDA_TW 8
+#define MSDA_TH 4
+#define MSDA_TILE 32           // positions per bin = one 32-register accumulator block per lane
 #define MSDA_CHUNK 4096
-#define MSDA_DRAIN_U 32
 typedef float f32x32_t __attribute__((ext_vector_type(32)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; };     // tiles of level l: [first_tile[l], first_tile[l+1])
+struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; int ntx[MSDA_MAX_L]; };   // tiles of level l: [first_tile[l], first_tile[l+1]), ntx per row
 
 struct MsdaWs {            // device workspace carved by the host wrapper
-  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int2* entries;   // ctrl[0] = total chunks, ctrl[2+x] = next chunk of XCD x's share
+  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int4* entries;   // ctrl[0] = total chunks, ctrl[2+x] = next chunk of XCD x's share
 };
 
 // Binning = a counting sort with workgroup-private LDS histograms (global integer atomics cost one L2 request per
@@ -420,7 +421,7 @@ struct MsdaWs {            // device workspace carved by the host wrapper
 // MSDA_SEG consecutive sampling points of one image, one point per lane per iteration (perfectly coalesced loc / attw).
 //   COUNT: hist[head*ntiles + tile]++ in LDS, then the histogram is stored to seg_hist[b][seg][.] and added to cnt[bin]
 //   FILL : LDS cursors start at the segment's exclusive offsets (seg_hist rewritten in place by msda_segscan_k) and
-//          hand out slots: entries[slot] = {query << 8 | position in tile, coef}
+//          hand out slots: records[slot] = {query << 7 | (ly+1) << 4 | (lx+1), weight, frac x, frac y}
 #define MSDA_SEG 65536
 template <bool FILL>
 __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
@@ -449,22 +450,24 @@ __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins,
     if (!(y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl)) continue;
     const float xf = floorf(x), yf = floorf(y);
     const int x0 = (int)xf, y0 = (int)yf;
-    const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;
+    const float ax = x - xf, ay = y - yf;
     const float wgt = FILL ? attw[pt] : 0.f;
+    const int ntx = bins.ntx[l];
     const int lb0 = head * ntiles + bins.first_tile[l];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
-      if (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) {
-        const int pos = yy * Wl + xx;
-        const int lb = lb0 + pos / MSDA_TILE;
-        const int slot = atomicAdd(&hist[lb], 1);        // LDS
+    // tile columns / rows that hold an in-image corner: the left column x0 (if >= 0) and the right column x0+1 (if < W)
+    const bool xa = x0 >= 0, xb = x0 + 1 < Wl, ya = y0 >= 0, yb = y0 + 1 < Hl;
+    const int txa = x0 >> 3, txb = (x0 + 1) >> 3, tya = y0 >> 2, tyb = (y0 + 1) >> 2;
+    const int tx_first = xa ? txa : txb, ty_first = ya ? tya : tyb;
+    const int two_x = (xa && xb && txb != txa) ? 1 : 0, two_y = (ya && yb && tyb != tya) ? 1 : 0;
+    for (int jy = 0; jy <= two_y; ++jy)
+      for (int jx = 0; jx <= two_x; ++jx) {
+        const int tx = jx ? txb : tx_first, ty = jy ? tyb : ty_first;
+        const int slot = atomicAdd(&hist[lb0 + ty * ntx + tx], 1);        // LDS
         if (FILL) {
-          const float cf = wgt * (((t >> 1) ? ay : by) * ((t & 1) ? ax : bx));
-          ws.entries[slot] = make_int2((q << 8) | (pos % MSDA_TILE), __float_as_int(cf));
+          const int lx1 = x0 - tx * MSDA_TW + 1, ly1 = y0 - ty * MSDA_TH + 1;   // top-left corner relative to the tile, +1: [0,8] x [0,4]
+          ws.entries[slot] = make_int4((q << 7) | (ly1 << 4) | lx1, __float_as_int(wgt), __float_as_int(ax), __float_as_int(ay));
         }
       }
-    }
   }
   if (!FILL) {
     __syncthreads();
@@ -518,16 +521,17 @@ __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
   if (threadIdx.x >= 1 && threadIdx.x < 2 + MSDA_XCDS) ws.ctrl[threadIdx.x] = 0;      // per-XCD work cursors
 }
 
-// drain: a wave owns one chunk (<= MSDA_CHUNK entries of one bin) and accumulates its tile in 32 VGPRs per lane
-// (lane == channel).  Measured on the first version, which consumed entries in arrival order with `acc[pos] += g * coef`
-// and pos as a dynamic register index: that costs 6 VALU + 5 SALU instructions per entry (v_readlane x2, index on/off,
-// v_mov / v_fmac / v_mov) and the kernel was VALU-issue bound (12.5 ms for the 8 x 352 x 1120 cross-attention).
-// Now each sub-chunk of MSDA_SUB entries is first counting-sorted BY POSITION in LDS — lane-parallel, ~0.2 instructions
-// per entry — and consumed run by run into ONE statically addressed accumulator: 3 VALU per entry (bf16 -> f32 shift,
-// v_readlane of the coefficient, v_fmac) and one LDS read (the lane's channel of the staged gradient row), all 32 reads of a
-// block issued before the first use; the dynamic register index is paid once per position run.  Gradient rows are fetched 16 bytes per lane (8 rows of 128 B per instruction for
-// bf16), double-buffered through a wave-private LDS stage.
-#define MSDA_SUB 1024
+// drain: a wave owns one chunk (<= MSDA_CHUNK records of one tile) and accumulates the tile in 32 VGPRs per lane
+// (lane == channel).  History (8 x 352 x 1120 cross-attention): v1 consumed (point, corner) entries in arrival order with
+// `acc[pos] += g * coef`, pos a dynamic register index: 6 VALU + 5 SALU per entry, VALU-issue bound, 12.5 ms.  v2 sorted
+// each sub-chunk by position in LDS and consumed run by run: 3 VALU per entry, then bound by the 4 gradient-row gathers
+// per sampling point.  v3 (this one) works on (point, tile) records: one gather per record, sub-chunks counting-sorted in
+// LDS by the corner class (ly+1)*9 + (lx+1) — lane-parallel, ~0.3 instructions per record — and consumed run by run into
+// four statically addressed accumulators (the 2 x 2 corners) with two packed FMAs per record.  Classes are visited in
+// raster order, so the right-hand pair of one class is the left-hand pair of the next: per class step two accumulators
+// are written to the register tile through `s_set_gpr_idx` and two are carried over.
+#define MSDA_SUB 768
+#define MSDA_NCLS 45           // (ly+1) in [0,4] x (lx+1) in [0,8]
 template <typename T>
 __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins, MsdaWs ws, const T* __restrict__ gout,
                                                     float* __restrict__ d_value, int nbins, int Nv, int Nq, int nH, int L) {
@@ -535,20 +539,22 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
   constexpr int LPR = 64 / CPLr;                       // lanes per gradient row: 8 (bf16) / 16 (fp32)
   constexpr int RPI = 64 / LPR;                        // rows per gather instruction: 8 / 4
   constexpr int NR = 32 / RPI;                         // gather instructions per 32-row block: 4 / 8
-  __shared__ __attribute__((aligned(16))) T stage_all[4 * 2 * 32 * 64];   // per wave: 2 buffers x 32 rows x 64 channels
-  __shared__ int s_q_all[4 * MSDA_SUB];
-  __shared__ float s_cf_all[4 * MSDA_SUB];
-  __shared__ int s_start_all[4 * 40];
+  __shared__ __attribute__((aligned(16))) T stage_all[4 * 32 * 64];   // per wave: 32 rows x 64 channels
+  __shared__ int s_key_all[4 * MSDA_SUB];
+  __shared__ float s_w_all[4 * MSDA_SUB], s_ax_all[4 * MSDA_SUB], s_ay_all[4 * MSDA_SUB];
+  __shared__ int s_start_all[4 * 64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  T* stage = stage_all + (size_t)wv * (2 * 32 * 64);
-  int* s_q = s_q_all + wv * MSDA_SUB;
-  float* s_cf = s_cf_all + wv * MSDA_SUB;
-  int* s_start = s_start_all + wv * 40;                // [0..31] run starts, [32] = n, [33] = never reached
+  T* stage = stage_all + (size_t)wv * (32 * 64);
+  int* s_key = s_key_all + wv * MSDA_SUB;
+  float* s_w = s_w_all + wv * MSDA_SUB;
+  float* s_ax = s_ax_all + wv * MSDA_SUB;
+  float* s_ay = s_ay_all + wv * MSDA_SUB;
+  int* s_start = s_start_all + wv * 64;                // [0..44] run starts, [45] = n, [46] = never reached
   const int gi = lane / LPR, subc = (lane % LPR) * CPLr;
   const int ntiles = bins.first_tile[L];
   const int total = ws.ctrl[0];
   // chunks are ordered by (image, head, tile): XCD x drains the x-th eighth of the list, so that neighbouring tiles — whose
-  // entries point at the same gradient rows — meet in one L2; a wave that runs dry helps the next partition
+  // records point at the same gradient rows — meet in one L2; a wave that runs dry helps the next partition
   const int part0 = blockIdx.x % MSDA_XCDS;
   int probe = 0;
   for (;;) {
@@ -570,112 +576,143 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
     const int chunk = item - ws.chunk_first[bin];
     const int cnt = ws.cnt[bin];
     const int e_lo = chunk * MSDA_CHUNK, e_hi = min(cnt, e_lo + MSDA_CHUNK);
-    const int2* ent = ws.entries + ws.offset[bin];
+    const int4* ent = ws.entries + ws.offset[bin];
     const int bh = bin / ntiles, tile = bin - bh * ntiles;
     const int b = bh / nH, head = bh - b * nH;
     int l = 0;
     while (l + 1 < L && tile >= bins.first_tile[l + 1]) ++l;
-    const int tile_lo = (tile - bins.first_tile[l]) * MSDA_TILE;
-    const int tile_n = min(MSDA_TILE, lv.H[l] * lv.W[l] - tile_lo);
+    const int tl = tile - bins.first_tile[l];
+    const int ty = tl / bins.ntx[l], tx = tl - ty * bins.ntx[l];
     const long rowbase = (long)b * Nq * nH + head;
 
     f32x32_t a0 = 0.f;
     for (int s_lo = e_lo; s_lo < e_hi; s_lo += MSDA_SUB) {
       const int n = min(MSDA_SUB, e_hi - s_lo);
-      // ---- counting sort of the sub-chunk by position (one entry per lane per step; LDS integer atomics are cheap)
+      // ---- counting sort of the sub-chunk by corner class (one record per lane per step; LDS integer atomics are cheap)
       __builtin_amdgcn_wave_barrier();
-      if (lane < 34) s_start[lane] = 0;
+      s_start[lane] = 0;
       __builtin_amdgcn_wave_barrier();
-      int2 E[MSDA_SUB / 64];
+      int4 E[MSDA_SUB / 64];
       int rank[MSDA_SUB / 64];
 #pragma unroll
       for (int i = 0; i < MSDA_SUB / 64; ++i) {
         const int idx = i * 64 + lane;
-        E[i] = make_int2(0, 0);
+        E[i] = make_int4(0, 0, 0, 0);
         rank[i] = 0;
         if (idx < n) {
           E[i] = ent[s_lo + idx];
-          rank[i] = atomicAdd(&s_start[E[i].x & 31], 1);
+          rank[i] = atomicAdd(&s_start[((E[i].x >> 4) & 7) * 9 + (E[i].x & 15)], 1);
         }
       }
       __builtin_amdgcn_wave_barrier();
       {
-        const int c = lane < 32 ? s_start[lane] : 0;
+        const int c = lane < MSDA_NCLS ? s_start[lane] : 0;
         int inc = c;
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(inc, d, 64); if ((lane & 31) >= d) inc += t; }
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
         __builtin_amdgcn_wave_barrier();
-        if (lane < 32) s_start[lane] = inc - c;
-        if (lane == 32) { s_start[32] = n; s_start[33] = 0x7fffffff; }
+        s_start[lane] = lane < MSDA_NCLS ? inc - c : (lane == MSDA_NCLS ? n : 0x7fffffff);
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < MSDA_SUB / 64; ++i) {
         const int idx = i * 64 + lane;
         if (idx < n) {
-          const int slot = s_start[E[i].x & 31] + rank[i];
-          s_q[slot] = E[i].x >> 8;
-          s_cf[slot] = __int_as_float(E[i].y);
+          const int slot = s_start[((E[i].x >> 4) & 7) * 9 + (E[i].x & 15)] + rank[i];
+          s_key[slot] = E[i].x;
+          s_w[slot] = __int_as_float(E[i].y);
+          s_ax[slot] = __int_as_float(E[i].z);
+          s_ay[slot] = __int_as_float(E[i].w);
         }
       }
-      const int nb = (n + 31) >> 5;                        // 32-entry blocks; pad the last one with coef 0 / query 0
-      if (n + lane < nb * 32 && lane < 32) { s_q[n + lane] = 0; s_cf[n + lane] = 0.f; }
+      const int nb = (n + 31) >> 5;                        // 32-record blocks; pad the last one with weight 0 / query 0
+      if (n + lane < nb * 32 && lane < 32) { s_key[n + lane] = 0; s_w[n + lane] = 0.f; s_ax[n + lane] = 0.f; s_ay[n + lane] = 0.f; }
       __builtin_amdgcn_wave_barrier();
 
-      // ---- gather (double-buffered) + run-wise accumulation
+      // ---- gather (next block in flight while this one is consumed) + run-wise accumulation
       u32x4_t R[NR];                                       // (HIP's uint4 struct kept this array in scratch)
 #define MSDA_GATHER(BLK)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                         \
-    const int q = s_q[(BLK) * 32 + i * RPI + gi];                                                          \
-    R[i] = *(const u32x4_t*)(gout + (rowbase + (long)q * nH) * 64 + subc);                                   \
+    const int q = s_key[(BLK) * 32 + i * RPI + gi] >> 7;                                                   \
+    R[i] = *(const u32x4_t*)(gout + (rowbase + (long)q * nH) * 64 + subc);                                 \
   }
-#define MSDA_PARK(BUF)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < NR; ++i) *(u32x4_t*)(stage + ((BUF) * 32 + i * RPI + gi) * 64 + subc) = R[i];
-      int pos = 0;
+#define MSDA_PARK()                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < NR; ++i) *(u32x4_t*)(stage + (i * RPI + gi) * 64 + subc) = R[i];
+      // a0[p] += v for a wave-uniform p, only when `ok` (a branch around it makes the compiler copy all 32 registers)
+#define MSDA_PUT(P_, OK_, V_) a0[(P_) & 31] += (OK_) ? (V_) : 0.f
+      int cls = 0;
       int run_end = __builtin_amdgcn_readfirstlane(s_start[1]);
-      float acc = 0.f;
+      f32x2_t accT = {0.f, 0.f}, accB = {0.f, 0.f};        // top pair (ly: lx, lx+1), bottom pair (ly+1: lx, lx+1)
       MSDA_GATHER(0)
-      MSDA_PARK(0)
+      MSDA_PARK()
       for (int blk = 0; blk < nb; ++blk) {
-        const int buf = blk & 1;
-        if (blk + 1 < nb) { MSDA_GATHER(blk + 1) }           // in flight while this block is consumed
-        const T* sp = stage + buf * 32 * 64 + lane;
         const int i0 = blk * 32;
-        // all 32 gradient values and the 32 coefficients (one per lane) are fetched up front: the run-boundary branches
-        // below would otherwise serialise every entry on an LDS round trip
+        // the 32 gradient values of this lane's channel are fetched up front: the run-boundary branches below would
+        // otherwise serialise every record on an LDS round trip; then the stage is free for the next block
         float gr[32];
 #pragma unroll
-        for (int k = 0; k < 32; ++k) gr[k] = Ld1<T>::ld(sp + k * 64);
-        const float cfl = s_cf[i0 + (lane & 31)];
+        for (int k = 0; k < 32; ++k) gr[k] = Ld1<T>::ld(stage + k * 64 + lane);
+        if (blk + 1 < nb) { MSDA_GATHER(blk + 1) }
+        // bilinear corner coefficients of record i0 + (lane & 31), zero for the corners that lie outside this tile
+        f32x2_t cT, cB;
+        {
+          const int j = i0 + (lane & 31);
+          const int key = s_key[j];
+          const float w = s_w[j], ax = s_ax[j], ay = s_ay[j];
+          const int lx = (key & 15) - 1, ly = ((key >> 4) & 7) - 1;
+          const float wl = lx >= 0 ? 1.f - ax : 0.f, wr = lx < MSDA_TW - 1 ? ax : 0.f;
+          const float wt = ly >= 0 ? w * (1.f - ay) : 0.f, wb = ly < MSDA_TH - 1 ? w * ay : 0.f;
+          cT = f32x2_t{wt * wl, wt * wr};
+          cB = f32x2_t{wb * wl, wb * wr};
+        }
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
           if (__builtin_expect(i0 + k == run_end, 0)) {      // wave-uniform and rare: keep the hot path fall-through
-            do {                                             // close the run of `pos` (and any empty runs behind it)
-              a0[pos & 31] += pos < 32 ? acc : 0.f;          // (a branch here makes the compiler copy all 32 registers)
-              acc = 0.f;
-              ++pos;
-              run_end = __builtin_amdgcn_readfirstlane(s_start[min(pos + 1, 33)]);
+            do {                                             // leave class `cls` (and any empty classes behind it)
+              const int ly = cls / 9 - 1, lx = cls % 9 - 1;
+              const bool in_cls = cls < MSDA_NCLS;
+              MSDA_PUT(ly * MSDA_TW + lx, in_cls && ly >= 0 && lx >= 0, accT.x);
+              MSDA_PUT((ly + 1) * MSDA_TW + lx, in_cls && ly < MSDA_TH - 1 && lx >= 0, accB.x);
+              // raster order: the right-hand pair becomes the left-hand pair of the next class of this tile row
+              const bool carry = lx < MSDA_TW - 1;
+              accT = f32x2_t{carry ? accT.y : 0.f, 0.f};
+              accB = f32x2_t{carry ? accB.y : 0.f, 0.f};
+              ++cls;
+              run_end = __builtin_amdgcn_readfirstlane(s_start[min(cls + 1, MSDA_NCLS + 1)]);
             } while (i0 + k == run_end);
           }
-          acc += readlane_f(cfl, k) * gr[k];
+          const float g = gr[k];
+          const f32x2_t g2 = {g, g};
+          accT += f32x2_t{readlane_f(cT.x, k), readlane_f(cT.y, k)} * g2;
+          accB += f32x2_t{readlane_f(cB.x, k), readlane_f(cB.y, k)} * g2;
         }
-        if (blk + 1 < nb) { MSDA_PARK(buf ^ 1) }
+        if (blk + 1 < nb) { MSDA_PARK() }
       }
-      a0[pos & 31] += pos < 32 ? acc : 0.f;
+      {                                                      // close the last open class: all four corners
+        const int ly = cls / 9 - 1, lx = cls % 9 - 1;
+        const bool in_cls = cls < MSDA_NCLS;
+        MSDA_PUT(ly * MSDA_TW + lx, in_cls && ly >= 0 && lx >= 0, accT.x);
+        MSDA_PUT((ly + 1) * MSDA_TW + lx, in_cls && ly < MSDA_TH - 1 && lx >= 0, accB.x);
+        MSDA_PUT(ly * MSDA_TW + lx + 1, in_cls && ly >= 0 && lx < MSDA_TW - 1, accT.y);
+        MSDA_PUT((ly + 1) * MSDA_TW + lx + 1, in_cls && ly < MSDA_TH - 1 && lx < MSDA_TW - 1, accB.y);
+      }
 #undef MSDA_GATHER
 #undef MSDA_PARK
+#undef MSDA_PUT
     }
-    float* dst = d_value + (((long)b * Nv + lv.start[l] + tile_lo) * nH + head) * 64 + lane;
+    // tile -> d_value rows (y, x) of level l; positions of a border tile that fall outside the map were never real
+    const int Wl = lv.W[l], Hl = lv.H[l];
+    float* dst = d_value + (((long)b * Nv + lv.start[l]) * nH + head) * 64 + lane;
     const long pstride = (long)nH * 64;
-#define MSDA_FLUSH(vec, base)                                                       \
-  _Pragma("unroll") for (int e = 0; e < 32; ++e) {                                   \
-    if ((base) + e < tile_n) {                                                       \
-      if (nchunk == 1) dst[((base) + e) * pstride] = vec[e];                         \
-      else atomicAdd(dst + ((base) + e) * pstride, vec[e]);                          \
-    }                                                                                \
-  }
-    MSDA_FLUSH(a0, 0)
-#undef MSDA_FLUSH
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const int y = ty * MSDA_TH + e / MSDA_TW, x = tx * MSDA_TW + e % MSDA_TW;
+      if (y < Hl && x < Wl) {
+        float* p = dst + ((long)y * Wl + x) * pstride;
+        if (nchunk == 1) *p = a0[e];
+        else atomicAdd(p, a0[e]);
+      }
+    }
   }
 }
 
@@ -684,10 +721,10 @@ static size_t msda_ws_layout(int nbins, long seg_hist_ints, long max_entries, ch
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_cnt = carve((size_t)nbins * 4), o_chk = carve((size_t)(nbins + 1) * 4);
   const size_t o_off = carve((size_t)(nbins + 1) * 8), o_ctrl = carve(64), o_sh = carve((size_t)seg_hist_ints * 4);
-  const size_t o_ent = carve((size_t)max_entries * 8);
+  const size_t o_ent = carve((size_t)max_entries * 16);
   if (ws) {
     ws->cnt = (int*)(base + o_cnt); ws->chunk_first = (int*)(base + o_chk); ws->offset = (long*)(base + o_off);
-    ws->ctrl = (int*)(base + o_ctrl); ws->seg_hist = (int*)(base + o_sh); ws->entries = (int2*)(base + o_ent);
+    ws->ctrl = (int*)(base + o_ctrl); ws->seg_hist = (int*)(base + o_sh); ws->entries = (int4*)(base + o_ent);
   }
   return off;
 }
@@ -701,12 +738,16 @@ static MsdaPlan msda_plan(const MsdaBins& bins, int B, int Nq, int nH, int L, in
   pl.max_entries = (long)B * npts_b * 4;
   const long nbins = (long)B * pl.nloc;
   pl.nbins = (int)nbins;
-  pl.ok = nbins < (1L << 30) && Nq < (1 << 23) && pl.max_entries < (1L << 31) && (size_t)pl.nloc * 4 <= 60 * 1024 && B <= 65535;
+  pl.ok = nbins < (1L << 30) && Nq < (1 << 24) && pl.max_entries < (1L << 31) && (size_t)pl.nloc * 4 <= 60 * 1024 && B <= 65535;
   return pl;
 }
 static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
   int n = 0;
-  for (int l = 0; l < L; ++l) { bins.first_tile[l] = n; n += (lv.H[l] * lv.W[l] + MSDA_TILE - 1) / MSDA_TILE; }
+  for (int l = 0; l < L; ++l) {
+    bins.first_tile[l] = n;
+    bins.ntx[l] = (lv.W[l] + MSDA_TW - 1) / MSDA_TW;
+    n += bins.ntx[l] * ((lv.H[l] + MSDA_TH - 1) / MSDA_TH);
+  }
   bins.first_tile[L] = n;
   return n;
 }
