@@ -275,6 +275,29 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
   }
 }
 
+// <gradient row piece, value row piece> over the 16 bytes a lane holds: 4 fp32 FMAs, or 4 x v_dot2c_f32_bf16 on the raw
+// bf16 pairs (no bf16 -> f32 unpacking: 16 instead of 64 VALU per sampling point for the four corners)
+typedef unsigned int lw_raw_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct RowDot;
+template <> struct RowDot<float> {
+  static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += __uint_as_float(a[i]) * __uint_as_float(b[i]);
+    return s;
+  }
+};
+template <> struct RowDot<bf16_t> {
+  static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]), __builtin_bit_cast(bf16x2_t, b[i]), s, false);
+    return s;
+  }
+};
+
 // d_loc / d_attw only (the binned path computes d_value separately): same 16-lane-group decomposition as the forward
 // kernel (4 channels per lane, one 16-byte / 8-byte load per tap and lane, four (query, head) pairs per wave), the three
 // per-point sums reduced over the group with a 4-step butterfly.
@@ -299,35 +322,33 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
     const float* lp = loc + g_ * (long)(LP * 2);
     const float* ap = attw + g_ * (long)LP;
     const T* vb = value + ((long)b * Nv * nH + head) * 64 + c0;
-    float go[CPL];
-    VecL<T>::ld(gout + g_ * 64 + c0, go);
+    const lw_raw_t go = *(const lw_raw_t*)(gout + g_ * 64 + c0);
+    // branch-free like the forward kernel: addresses are clamped into the map and out-of-range corners / points get a zero
+    // mask, so the four 16-byte loads of several points are in flight together instead of one point per round trip
 #define MSDA_LW_POINT(j_, sv_, sx_, sy_)                                                                  \
     {                                                                                                     \
       const float2 xy = *(const float2*)(lp + 2 * (j_));                                                  \
       const float wgt = ap[(j_)];                                                                         \
       const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;                               \
-      float s_val = 0.f, s_dx = 0.f, s_dy = 0.f;                                                          \
-      if (live && y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl) {                               \
-        const float xf = floorf(x), yf = floorf(y);                                                       \
-        const int x0 = (int)xf, y0 = (int)yf;                                                             \
-        const float ax = x - xf, ay = y - yf, bx = 1.f - ax, by = 1.f - ay;                               \
-        const int xa = max(x0, 0), xb = min(x0 + 1, Wl - 1), ya = max(y0, 0), yb = min(y0 + 1, Hl - 1);   \
-        const float m_xa = x0 >= 0 ? 1.f : 0.f, m_xb = x0 + 1 < Wl ? 1.f : 0.f;                           \
-        const float m_ya = y0 >= 0 ? 1.f : 0.f, m_yb = y0 + 1 < Hl ? 1.f : 0.f;                           \
-        float v00[CPL], v01[CPL], v10[CPL], v11[CPL];                                                     \
-        VecL<T>::ld(vl + ((long)ya * Wl + xa) * nH * 64, v00);                                            \
-        VecL<T>::ld(vl + ((long)ya * Wl + xb) * nH * 64, v01);                                            \
-        VecL<T>::ld(vl + ((long)yb * Wl + xa) * nH * 64, v10);                                            \
-        VecL<T>::ld(vl + ((long)yb * Wl + xb) * nH * 64, v11);                                            \
-        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;                                                 \
-        _Pragma("unroll") for (int i = 0; i < CPL; ++i) {                                                 \
-          d00 += go[i] * v00[i]; d01 += go[i] * v01[i]; d10 += go[i] * v10[i]; d11 += go[i] * v11[i];     \
-        }                                                                                                 \
-        d00 *= m_ya * m_xa; d01 *= m_ya * m_xb; d10 *= m_yb * m_xa; d11 *= m_yb * m_xb;                    \
-        s_val = by * bx * d00 + by * ax * d01 + ay * bx * d10 + ay * ax * d11;                            \
-        s_dx = by * (d01 - d00) + ay * (d11 - d10);                                                       \
-        s_dy = bx * (d10 - d00) + ax * (d11 - d01);                                                       \
-      }                                                                                                   \
+      const bool in = live && y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl;                     \
+      const float xc = fminf(fmaxf(x, -1.f), (float)Wl), yc = fminf(fmaxf(y, -1.f), (float)Hl);           \
+      const float xf = floorf(xc), yf = floorf(yc);                                                       \
+      const int x0 = (int)xf, y0 = (int)yf;                                                               \
+      const float ax = xc - xf, ay = yc - yf, bx = 1.f - ax, by = 1.f - ay;                               \
+      const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);                           \
+      const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);                           \
+      const bool k_xa = in && x0 >= 0, k_xb = in && x0 + 1 < Wl, k_ya = y0 >= 0, k_yb = y0 + 1 < Hl;      \
+      const lw_raw_t r00 = *(const lw_raw_t*)(vl + ((long)ya * Wl + xa) * nH * 64);                        \
+      const lw_raw_t r01 = *(const lw_raw_t*)(vl + ((long)ya * Wl + xb) * nH * 64);                        \
+      const lw_raw_t r10 = *(const lw_raw_t*)(vl + ((long)yb * Wl + xa) * nH * 64);                        \
+      const lw_raw_t r11 = *(const lw_raw_t*)(vl + ((long)yb * Wl + xb) * nH * 64);                        \
+      float d00 = RowDot<T>::dot(go, r00), d01 = RowDot<T>::dot(go, r01);                                 \
+      float d10 = RowDot<T>::dot(go, r10), d11 = RowDot<T>::dot(go, r11);                                 \
+      d00 = (k_ya && k_xa) ? d00 : 0.f; d01 = (k_ya && k_xb) ? d01 : 0.f;   /* selects: a masked corner may hold anything */ \
+      d10 = (k_yb && k_xa) ? d10 : 0.f; d11 = (k_yb && k_xb) ? d11 : 0.f;                                 \
+      const float s_val = by * bx * d00 + by * ax * d01 + ay * bx * d10 + ay * ax * d11;                  \
+      const float s_dx = by * (d01 - d00) + ay * (d11 - d10);                                             \
+      const float s_dy = bx * (d10 - d00) + ax * (d11 - d01);                                             \
       sv_ = s_val; sx_ = s_dx * (wgt * (float)Wl); sy_ = s_dy * (wgt * (float)Hl);                        \
     }
     for (int l = 0; l < L; ++l) {
