@@ -20,6 +20,8 @@ class PatchEmbedSwin(BaseModule):
                                            out_channels=embed_dims, kernel_size=kernel_size, stride=stride,
                                            padding=padding, dilation=dilation)
         self.norm = build_norm_layer(norm_cfg, embed_dims)[1] if norm_cfg is not None else None
+        if self.norm is not None and hasattr(self.norm, 'autocast_out'):
+            self.norm.autocast_out = False          # its output is the fp32 residual stream of stage 0 (as under plain autocast)
         self.DH = self.DW = None
 
     def forward(self, x):

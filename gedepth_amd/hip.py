@@ -33,6 +33,8 @@ SIGNATURES = {
     'ge_map_from_tokens': (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _l, _f, _u64, _i, _vp]),
     'ge_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_layernorm_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _f, _vp]),
+    'ge_layernorm_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     'ge_bias_act_fwd': (_i, [_vp, _vp, _i, _i, _l, _f, _i, _vp]),
     'ge_bias_act_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp]),
     'ge_ground_embed_fwd': (_i, [_vp, _vp, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -377,6 +377,47 @@ def bilinear_resize(x, size, align_corners=False):
     return _Bilinear.apply(x, Ho, Wo, bool(align_corners))
 
 
+# ------------------------------------------------------------------------------ layer norm
+class _LayerNorm(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        x = _c(x)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        w, b = _c(weight.detach().to(_f32)), _c(bias.detach().to(_f32))
+        y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        mean = torch.empty(rows, device=x.device, dtype=_f32)
+        rstd = torch.empty(rows, device=x.device, dtype=_f32)
+        PROFILER.run(f'layernorm_fwd[{rows}x{C} {_tag(x)}->{_tag(y)}]', x.numel() * _es(x) + y.numel() * _es(y), lambda: hip.check(
+            hip.lib().ge_layernorm_fwd(hip.ptr(x, name='x'), hip.dtype_code(x), hip.ptr(w), hip.ptr(b), hip.ptr(y),
+                                       hip.dtype_code(y), hip.ptr(mean), hip.ptr(rstd), rows, C, eps, hip.stream()),
+            'ge_layernorm_fwd'))
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = _c(dy)
+        if dy.dtype not in (_f32, torch.bfloat16):
+            dy = dy.to(_f32)
+        dx = torch.empty_like(x)
+        dwb = torch.zeros(2, C, device=x.device, dtype=_f32)
+        PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}]', 2 * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
+            hip.lib().ge_layernorm_bwd(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
+                                       hip.ptr(rstd), hip.ptr(dx), hip.ptr(dwb[0]), hip.ptr(dwb[1]), rows, C, hip.stream()),
+            'ge_layernorm_bwd'))
+        return dx, dwb[0], dwb[1], None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
+    """LayerNorm over the last dim; x f32/bf16, statistics f32, output ``out_dtype`` (default: x.dtype)."""
+    return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype or x.dtype)
+
+
 # ------------------------------------------------------------------------- bias + activation
 class _BiasAct(torch.autograd.Function):
 

@@ -102,9 +102,28 @@ class ModuleList(BaseModule, nn.ModuleList):
 
 
 # ----------------------------------------------------------------------------------- layers
+class LayerNorm(nn.LayerNorm):
+    """``nn.LayerNorm`` (same parameters / state-dict keys) running as one mixed-precision HIP kernel on MI355X: bf16 or
+    fp32 tokens in, fp32 statistics, and — under autocast — bf16 out for the Linear that follows, instead of ATen's
+    copy-to-fp32 / fp32 LayerNorm / copy-to-bf16 (gedepth_amd/csrc/norm.hip).  ``autocast_out = False`` keeps the fp32 output
+    autocast would give (the patch-embed norm, whose output is the fp32 residual stream of stage 0)."""
+    autocast_out = True
+
+    def forward(self, x):
+        C = x.shape[-1]
+        if (x.is_cuda and self.elementwise_affine and len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 3072
+                and x.dtype in (torch.float32, torch.bfloat16)):
+            from .. import kernels
+            out_dtype = x.dtype
+            if torch.is_autocast_enabled():
+                out_dtype = torch.get_autocast_dtype('cuda') if self.autocast_out else torch.float32
+            return kernels.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
+        return super().forward(x)
+
+
 _NORM = {
     'BN': ('bn', nn.BatchNorm2d), 'BN1d': ('bn', nn.BatchNorm1d), 'BN2d': ('bn', nn.BatchNorm2d),
-    'SyncBN': ('bn', nn.SyncBatchNorm), 'GN': ('gn', nn.GroupNorm), 'LN': ('ln', nn.LayerNorm),
+    'SyncBN': ('bn', nn.SyncBatchNorm), 'GN': ('gn', nn.GroupNorm), 'LN': ('ln', LayerNorm),
     'IN': ('in', nn.InstanceNorm2d),
 }
 _ACT = {

@@ -138,6 +138,18 @@ int ge_map_from_tokens(const void* tok, long tok_bs, const void* res, long res_b
                        long N, float p_drop, unsigned long long seed, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension of a (rows, C) token matrix with mixed precision I/O: x / dx in x_dtype, y / dy in
+ * y_dtype (each GE_F32 or GE_BF16), gamma / beta / mean / rstd / dgamma / dbeta f32.  Replaces F.layer_norm on the Swin
+ * token path (depthformer_swin.py:461-472 norm1 / norm2, :98-122 PatchMerging.norm, :1166-1172 stage norms;
+ * utils/embed.py:282-302) together with the dtype copies autocast puts around it.  C % 4 == 0, C <= 3072.
+ * Backward: dgamma / dbeta are ACCUMULATED (zero-fill them first).
+ */
+int ge_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                     float* mean, float* rstd, long rows, int C, float eps, void* stream);
+int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                     const float* rstd, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bias + activation after a bias-free convolution, NCHW, in place: x = act(x + bias[c]) with
  * act = leaky-relu(slope) (slope 0 = ReLU, 1 = identity).  Replaces the broadcast bias add + activation kernels of
  * mmcv ConvModule without norm (decode_heads/densedepth_head.py:14-27) and of the PE-neck convs

@@ -511,6 +511,50 @@ def test_concat_tokens_map_token_slice_and_dropout(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('C', [96, 192, 384, 768, 1536, 3072, 100])
+@pytest.mark.parametrize('io', ['f32->f32', 'f32->bf16', 'bf16->bf16', 'bf16->f32'])
+def test_layer_norm_mixed_precision(dev, C, io):
+    """F.layer_norm on the Swin token path (norm1 / norm2 / PatchMerging.norm / stage norms) with the dtype copies autocast
+    puts around it folded in; forward and all three gradients against the fp32 ATen op on the same stored values."""
+    from gedepth_amd.kernels import layer_norm
+    tin, tout = (torch.float32 if t == 'f32' else torch.bfloat16 for t in io.split('->'))
+    rows = (3, 37)
+    g = gen(21)
+    x = (torch.randn(*rows, C, generator=g) * 2 + 0.5).to(tin)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    go = torch.randn(*rows, C, generator=g).to(tout)
+    xc, wc, bc = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xc, (C,), wc, bc, 1e-5)
+    ref.backward(go.float())
+    xg, wg, bg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = layer_norm(xg, wg, bg, 1e-5, tout)
+    assert out.dtype == tout and xg.shape == out.shape
+    out.backward(go.to(dev))
+    assert xg.grad.dtype == tin
+    t_out = dict(rtol=2 ** -7, atol=2 ** -7) if tout == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    close(out.float(), ref, what='y', **t_out)
+    if tin == torch.bfloat16:
+        assert (xg.grad.float().cpu() - xc.grad).abs().max() <= 2 ** -7 * xc.grad.abs().max()
+    else:
+        close_scaled(xg.grad, xc.grad, what='dx')
+    close_scaled(wg.grad, wc.grad, what='dgamma')
+    close_scaled(bg.grad, bc.grad, what='dbeta')
+
+
+@pytest.mark.gpu
+def test_layer_norm_module_follows_autocast(dev):
+    from gedepth_amd.mmrt.bricks import build_norm_layer
+    ln = build_norm_layer(dict(type='LN'), 96)[1].to(dev)
+    x = torch.randn(2, 50, 96, device=dev)
+    assert ln(x).dtype == torch.float32
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert ln(x).dtype == torch.bfloat16 and ln(x.bfloat16()).dtype == torch.bfloat16
+        ln.autocast_out = False
+        assert ln(x.bfloat16()).dtype == torch.float32
+    assert torch.allclose(ln(x), F.layer_norm(x, (96,), ln.weight, ln.bias, ln.eps), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 5, 7, 9), (2, 16, 12, 16), (1, 3, 1, 1)])
 @pytest.mark.parametrize('slope', [1.0, 0.0, 0.01])
 def test_bias_act_fp32(dev, shape, slope):

@@ -78,10 +78,15 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
             gr = gr[::max(1, gr.numel() // 50000)].cpu()
             refg = T(g[k])
             l2rel = ((gr - refg).norm() / (refg.norm() + 1e-30)).item()
-            # Swin-T: ~1e-5 everywhere.  Swin-L (24 blocks, fill-rule weights): ~6e-3 on the backbone gradients although
-            # the losses agree to 1e-7 and every conv / linear / norm layer's own backward agrees to 1e-6 with a float64
-            # CPU recomputation (scratch probes, DESIGN.md "open items") — bounded here, tracked there.
-            tol = 2e-4 if 'T' in tag else 1.5e-2
+            # Swin-T: <= 5e-5 everywhere except four stage-0 tensors at ~4e-4 since LayerNorm runs as the HIP kernel (2.5e-5
+            # with ATen's): qkv.bias / relative_position_bias_table of blocks 0-1 — directions the softmax is invariant to,
+            # whose gradients are sums that cancel to rounding level — and the patch-embed weight behind them.  The kernel is
+            # closer to float64 than ATen's on every LayerNorm of this model (7e-8 vs 8e-8 rel. l2, forward and backward,
+            # scratch/dbg_ln3.py); the fixture comes from CPU kernels that round like ATen's.
+            # Swin-L (24 blocks, fill-rule weights): ~6e-3 on the backbone gradients although the losses agree to 1e-7 and
+            # every conv / linear / norm layer's own backward agrees to 1e-6 with a float64 CPU recomputation (scratch
+            # probes, DESIGN.md "open items") — the same sensitivity; bounded here, tracked there.
+            tol = 1e-3 if 'T' in tag else 1.5e-2
             assert l2rel <= tol, (k, l2rel)
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())).item()
     assert abs(total - float(g['grad_norm_total'])) <= (2e-4 if 'T' in tag else 5e-3) * float(g['grad_norm_total'])
