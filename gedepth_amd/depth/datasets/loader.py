@@ -7,10 +7,20 @@ from ...mmrt.runner import get_dist_info
 
 
 def collate(samples):
+    """Train samples: tensors stacked, ``img_metas`` a list of dicts.  Test-time-augmentation samples (every value a list
+    over augmentations, pipelines/test_time_aug.py): a list over augmentations of stacked tensors / meta lists — the
+    ``forward_test(imgs, img_metas)`` protocol of depther/base.py:64-90."""
     out = {}
     for k in samples[0]:
         vals = [s[k] for s in samples]
-        if k == 'img_metas':
+        if isinstance(vals[0], list):                     # TTA: transpose [sample][aug] -> [aug][sample]
+            n_aug = len(vals[0])
+            per_aug = [[v[a] for v in vals] for a in range(n_aug)]
+            if k == 'img_metas':
+                out[k] = per_aug
+            else:
+                out[k] = [torch.stack(a, 0) if torch.is_tensor(a[0]) else torch.as_tensor(a) for a in per_aug]
+        elif k == 'img_metas':
             out[k] = vals
         elif torch.is_tensor(vals[0]):
             out[k] = torch.stack(vals, 0)

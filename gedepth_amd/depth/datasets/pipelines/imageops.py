@@ -1,0 +1,131 @@
+"""cv2-free numpy restatements of the ``mmcv.image`` functions the KITTI pipeline calls (mmcv 1.3.13, cv2 backend):
+``imflip``, ``imnormalize``, ``rescale_size`` / ``imrescale`` / ``imresize`` and ``imrotate``.  The reference uses them in
+depth/datasets/pipelines/transforms.py:30-47 (Normalize), :249-286 (RandomRotate), :321-350 (RandomFlip), :655-693 (Resize)
+and loading.py:146 (nearest resize of the slope-class map).
+
+Parity status: cv2 is not installed in the build image, so these are restated from OpenCV's documented sampling rules
+(half-pixel-centre bilinear without antialiasing, ``floor(dst * scale)`` nearest, inverse-mapped affine warp with a
+constant border) and are NOT pinned against cv2 output; OpenCV's warpAffine additionally quantises source coordinates to
+1/32 pixel, which is not reproduced.
+"""
+import numpy as np
+
+_INTERP = ('nearest', 'bilinear')
+
+
+def imflip(img, direction='horizontal'):
+    assert direction in ('horizontal', 'vertical', 'diagonal')
+    if direction == 'horizontal':
+        return np.flip(img, axis=1)
+    if direction == 'vertical':
+        return np.flip(img, axis=0)
+    return np.flip(img, axis=(0, 1))
+
+
+def imnormalize(img, mean, std, to_rgb=True):
+    """(img[BGR->RGB] - mean) / std in float32 (mmcv multiplies by the float64 reciprocal of std)."""
+    img = np.asarray(img).astype(np.float32)
+    if to_rgb:
+        img = img[..., ::-1]
+    mean = np.float64(np.asarray(mean).reshape(1, -1))
+    stdinv = 1 / np.float64(np.asarray(std).reshape(1, -1))
+    return ((img - mean) * stdinv).astype(np.float32)
+
+
+def rescale_size(old_size, scale, return_scale=False):
+    """mmcv.rescale_size: ``scale`` is a factor or a (long edge, short edge) bound; sizes are (w, h)."""
+    w, h = old_size
+    if isinstance(scale, (float, int)):
+        if scale <= 0:
+            raise ValueError(f'Invalid scale {scale}, must be positive.')
+        scale_factor = scale
+    elif isinstance(scale, tuple):
+        max_long_edge, max_short_edge = max(scale), min(scale)
+        scale_factor = min(max_long_edge / max(h, w), max_short_edge / min(h, w))
+    else:
+        raise TypeError(f'Scale must be a number or tuple of int, but got {type(scale)}')
+    new_size = (int(w * float(scale_factor) + 0.5), int(h * float(scale_factor) + 0.5))
+    return (new_size, scale_factor) if return_scale else new_size
+
+
+def _resize_axis_bilinear(n_in, n_out):
+    src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+    i0 = np.floor(src).astype(np.int64)
+    w1 = (src - i0).astype(np.float32)
+    return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), w1
+
+
+def imresize(img, size, return_scale=False, interpolation='bilinear'):
+    """Resize to ``size`` = (w, h).  bilinear: half-pixel centres, edge replication, no antialiasing (cv2.INTER_LINEAR);
+    nearest: ``src = min(floor(dst * in / out), in - 1)`` (cv2.INTER_NEAREST)."""
+    assert interpolation in _INTERP
+    h, w = img.shape[:2]
+    ow, oh = int(size[0]), int(size[1])
+    if interpolation == 'nearest':
+        ys = np.minimum(np.floor(np.arange(oh) * (h / oh)).astype(np.int64), h - 1)
+        xs = np.minimum(np.floor(np.arange(ow) * (w / ow)).astype(np.int64), w - 1)
+        out = img[ys][:, xs]
+    else:
+        src = img.astype(np.float32) if img.dtype != np.float64 else img
+        y0, y1, wy = _resize_axis_bilinear(h, oh)
+        x0, x1, wx = _resize_axis_bilinear(w, ow)
+        wy = wy.reshape((-1, 1) + (1,) * (img.ndim - 2))
+        wx = wx.reshape((1, -1) + (1,) * (img.ndim - 2))
+        top = src[y0][:, x0] * (1 - wx) + src[y0][:, x1] * wx
+        bot = src[y1][:, x0] * (1 - wx) + src[y1][:, x1] * wx
+        out = top * (1 - wy) + bot * wy
+        if img.dtype == np.uint8:
+            out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+        else:
+            out = out.astype(img.dtype)
+    if return_scale:
+        return out, ow / w, oh / h
+    return out
+
+
+def imrescale(img, scale, return_scale=False, interpolation='bilinear'):
+    h, w = img.shape[:2]
+    new_size, scale_factor = rescale_size((w, h), scale, return_scale=True)
+    out = imresize(img, new_size, interpolation=interpolation)
+    return (out, scale_factor) if return_scale else out
+
+
+def imrotate(img, angle, center=None, scale=1.0, border_value=0, interpolation='bilinear', auto_bound=False):
+    """Rotate clockwise by ``angle`` degrees about ``center`` (default: the image centre), output size = input size:
+    ``cv2.warpAffine(img, cv2.getRotationMatrix2D(center, -angle, scale), (w, h), borderValue=border_value)``."""
+    assert interpolation in _INTERP
+    if auto_bound:
+        raise NotImplementedError('auto_bound is not used on the GEDepth path')
+    h, w = img.shape[:2]
+    cx, cy = ((w - 1) * 0.5, (h - 1) * 0.5) if center is None else center
+    a = np.deg2rad(-angle)
+    alpha, beta = scale * np.cos(a), scale * np.sin(a)
+    m = np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
+    # dst(x, y) = src(M^-1 (x, y)): invert the 2x3 affine
+    det = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    inv = np.array([[m[1, 1], -m[0, 1]], [-m[1, 0], m[0, 0]]]) / det
+    off = -inv @ m[:, 2]
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    sx = inv[0, 0] * xs + inv[0, 1] * ys + off[0]
+    sy = inv[1, 0] * xs + inv[1, 1] * ys + off[1]
+    squeeze = img.ndim == 2
+    src = img[..., None] if squeeze else img
+    border = np.broadcast_to(np.asarray(border_value, dtype=np.float64), (src.shape[2],)) if np.ndim(border_value) else \
+        np.full((src.shape[2],), float(border_value))
+
+    def fetch(yi, xi):
+        inside = (yi >= 0) & (yi < h) & (xi >= 0) & (xi < w)
+        v = src[np.clip(yi, 0, h - 1), np.clip(xi, 0, w - 1)].astype(np.float64)
+        return np.where(inside[..., None], v, border)
+
+    if interpolation == 'nearest':
+        out = fetch(np.floor(sy + 0.5).astype(np.int64), np.floor(sx + 0.5).astype(np.int64))
+    else:
+        x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+        fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+        out = (fetch(y0, x0) * (1 - fx) + fetch(y0, x0 + 1) * fx) * (1 - fy) + \
+              (fetch(y0 + 1, x0) * (1 - fx) + fetch(y0 + 1, x0 + 1) * fx) * fy
+    if img.dtype == np.uint8:
+        out = np.clip(np.rint(out), 0, 255)
+    out = out.astype(img.dtype)
+    return out[..., 0] if squeeze else out

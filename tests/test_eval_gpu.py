@@ -1,0 +1,75 @@
+"""The KITTI evaluation and training entry points end to end on MI355X with the toy tree."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from gedepth_amd.depth.apis.test import single_gpu_test                      # noqa: E402
+from gedepth_amd.depth.datasets import build_dataloader, build_dataset      # noqa: E402
+from gedepth_amd.depth.models import build_depther                           # noqa: E402
+from gedepth_amd.mmrt.config import Config                                   # noqa: E402
+from gedepth_amd.mmrt.optim import build_optimizer                           # noqa: E402
+from toy_kitti import make_toy_kitti                                         # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def setup(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp('kitti'))
+    split = make_toy_kitti(root)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    for part in ('train', 'val', 'test'):
+        cfg.data[part].data_root = root
+        cfg.data[part].split = split
+    cfg.model.pretrained = None
+    torch.manual_seed(0)
+    model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    model.init_weights()
+    return cfg, model.cuda()
+
+
+def test_eigen_protocol_with_flip_tta(setup):
+    cfg, model = setup
+    ds = build_dataset(cfg.data.test, dict(test_mode=True))
+    loader = build_dataloader(ds, 1, 0, dist=False, shuffle=False)
+    preds = single_gpu_test(model, loader, pre_eval=False)
+    assert len(preds) == 4 and preds[0].shape == (1, 352, 1216) and np.isfinite(preds[0]).all()
+    assert preds[0].min() >= 1e-3 and preds[0].max() <= 80.0                     # clamped to the configured depth range
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        res = single_gpu_test(model, loader, pre_eval=True)
+    summary = ds.evaluate(res)
+    assert len(res) == 4 and all(np.isfinite(v) for v in summary.values()) and 0 <= summary['a1'] <= 1
+    # flip-TTA really averages the two views: a single un-flipped view gives a different map
+    batch = next(iter(loader))
+    with torch.no_grad():
+        single = model([batch['img'][0].cuda()], [batch['img_metas'][0]], return_loss=False,
+                       pe_ori_point=[batch['pe_ori_point'][0].cuda()])[0]
+        flipped = model([batch['img'][1].cuda()], [batch['img_metas'][1]], return_loss=False,
+                        pe_ori_point=[batch['pe_ori_point'][1].cuda()])[0]
+    assert np.allclose(preds[0], 0.5 * (single + flipped), rtol=1e-4, atol=1e-4)
+
+
+def test_train_step_on_pipeline_batch(setup):
+    cfg, model = setup
+    random.seed(0); np.random.seed(0)
+    ds = build_dataset(cfg.data.train)
+    loader = build_dataloader(ds, 2, 0, dist=False, shuffle=False, drop_last=True)
+    batch = next(iter(loader))
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert batch['img'].shape == (2, 5, 352, 704)
+    model.train()
+    opt = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    opt.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model.train_step(batch, opt)
+    out['loss'].backward()
+    opt.step()
+    assert np.isfinite(float(out['log_vars']['loss']))

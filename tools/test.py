@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Evaluate / run a depther — CLI of the reference's tools/test.py:21-68 (config, checkpoint, --eval, --options).
 
-The KITTI Eigen evaluation loop (dataset, Garg crop, flip TTA collation) is the next scope row;
-this entry point already covers model construction, checkpoint loading in the mmcv layout, the ``forward_test``
-protocol (``return_loss=False``, flip test-time augmentation) and the metric code on synthetic KITTI-shaped inputs.
+With a KITTI tree at ``cfg.data.test.data_root`` this is the Eigen-split protocol of the reference: test pipeline with
+flip test-time augmentation, ``forward_test`` (``return_loss=False``), KB crop + Garg crop, per-image metrics, nan-mean
+summary (gedepth_amd/depth/apis/test.py, gedepth_amd/depth/datasets/kitti.py).  ``--synthetic N`` runs the same model
+protocol on N synthetic KITTI-shaped inputs instead (no dataset needed).
 """
 import argparse
 import os.path as osp
@@ -27,8 +28,9 @@ def main():
     p.add_argument('checkpoint', nargs='?', default=None)
     p.add_argument('--eval', nargs='+', default=None)
     p.add_argument('--options', nargs='+', default=None)
-    p.add_argument('--synthetic', type=int, default=2)
+    p.add_argument('--synthetic', type=int, default=2, help='N synthetic inputs; 0 = evaluate cfg.data.test')
     p.add_argument('--flip-tta', action='store_true')
+    p.add_argument('--bf16', action='store_true', help='bf16 autocast inference')
     args = p.parse_args()
     cfg = Config.fromfile(args.config)
     if args.options:
@@ -39,6 +41,16 @@ def main():
     if args.checkpoint:
         load_checkpoint(model, args.checkpoint, map_location='cpu')
     model = model.cuda().eval()
+    data_root = cfg.data.test.get('data_root')
+    if args.synthetic <= 0 or (args.synthetic == 2 and data_root and osp.isdir(data_root) and args.eval):
+        from gedepth_amd.depth.apis.test import single_gpu_test
+        from gedepth_amd.depth.datasets import build_dataloader, build_dataset
+        dataset = build_dataset(cfg.data.test, dict(test_mode=True))
+        loader = build_dataloader(dataset, 1, cfg.data.workers_per_gpu, dist=False, shuffle=False)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=args.bf16):
+            results = single_gpu_test(model, loader, pre_eval=True)
+        dataset.evaluate(results)
+        return
     res = []
     for i in range(args.synthetic):
         b = synthetic_batch(1, 352, 1120, seed=100 + i, device='cuda', valid_fraction=0.05)

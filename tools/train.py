@@ -5,8 +5,8 @@
     python tools/train.py configs/depthformer/depthformer_swint_v.py --synthetic 64 --options runner.max_iters=20
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
 
-The KITTI / DDAD data pipelines are the next scope row; until they land, ``--synthetic N`` trains on N
-seeded KITTI-shaped samples (gedepth_amd/depth/datasets/synthetic.py).
+Without ``--synthetic`` the KITTI tree named by ``cfg.data`` is used (gedepth_amd/depth/datasets/kitti.py, SURVEY.md §8
+f1); ``--synthetic N`` trains on N seeded KITTI-shaped samples instead (gedepth_amd/depth/datasets/synthetic.py).
 """
 import argparse
 import os
@@ -80,14 +80,26 @@ def main():
         cfg.model.pretrained = None
     model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     model.init_weights()
-    if args.synthetic <= 0:
-        raise NotImplementedError('real-dataset pipelines are the next scope row (SURVEY.md §8 f1); use --synthetic N')
-    h, w = cfg.get('crop_size', (352, 1120))
-    dataset = SyntheticKITTI(args.synthetic, h, w, adaptive='dynamic_pe_neck' in cfg.model, seed=1234)
+    evaluate_fn = None
+    if args.synthetic > 0:
+        h, w = cfg.get('crop_size', (352, 1120))
+        dataset = SyntheticKITTI(args.synthetic, h, w, adaptive='dynamic_pe_neck' in cfg.model, seed=1234)
+    else:                                                     # the KITTI tree of cfg.data (depth/datasets/kitti.py)
+        from gedepth_amd.depth.apis.test import multi_gpu_test
+        from gedepth_amd.depth.datasets import build_dataloader, build_dataset
+        dataset = build_dataset(cfg.data.train)
+        if not args.no_validate:
+            val_set = build_dataset(cfg.data.val, dict(test_mode=True))
+            val_loader = build_dataloader(val_set, 1, cfg.data.workers_per_gpu, dist=distributed, shuffle=False)
+
+            def evaluate_fn(runner):
+                res = multi_gpu_test(runner.model, val_loader, pre_eval=True)
+                runner.model.train()
+                return val_set.evaluate(res, logger=None) if res is not None else None
     meta = dict(gedepth_amd_version=__version__, config=cfg.pretty_text, seed=args.seed)
     log = (lambda m: print(m, flush=True)) if rank == 0 else (lambda m: None)
     train_depther(model, dataset, cfg, distributed=distributed, validate=not args.no_validate, timestamp=timestamp,
-                  meta=meta, logger=log)
+                  meta=meta, logger=log, evaluate_fn=evaluate_fn)
 
 
 if __name__ == '__main__':
