@@ -10,24 +10,36 @@
 #include "common.h"
 
 // ====================================================================================== bilinear
-template <typename T>
+// Forward: a lane produces VN consecutive outputs of one row (one 16-byte store, the row interpolation weights and the
+// 64-bit index split paid once); the 2 x (VN + 1) input taps are neighbours and come from L1.
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) bilinear_fwd_k(const T* __restrict__ in, T* __restrict__ out, int NC,
                                                       int Hi, int Wi, int Ho, int Wo, int align, int C,
                                                       long in_bs, long in_ps, long out_bs, long out_ps) {
+  constexpr int VN = VEC ? V8<T>::N : 1;
   const float sy = ge_scale(Hi, Ho, align), sx = ge_scale(Wi, Wo, align);
-  const long total = (long)NC * Ho * Wo;
+  const int Wg = Wo / VN;                                   // VEC: Wo % VN == 0 (checked by the launcher)
+  const long total = (long)NC * Ho * Wg;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    int x = (int)(idx % Wo);
-    long t = idx / Wo;
-    int y = (int)(t % Ho);
-    long nc = t / Ho;
-    Lerp ly = ge_lerp(y, Hi, sy, align), lx = ge_lerp(x, Wi, sx, align);
+    const int x = (int)(idx % Wg) * VN;
+    long t = idx / Wg;
+    const int y = (int)(t % Ho);
+    const long nc = t / Ho;
+    const Lerp ly = ge_lerp(y, Hi, sy, align);
     const long n_ = nc / C, c_ = nc - n_ * C;
-    const T* p = in + n_ * in_bs + c_ * in_ps;
-    float v00 = Io<T>::ld(p + (long)ly.i0 * Wi + lx.i0), v01 = Io<T>::ld(p + (long)ly.i0 * Wi + lx.i1);
-    float v10 = Io<T>::ld(p + (long)ly.i1 * Wi + lx.i0), v11 = Io<T>::ld(p + (long)ly.i1 * Wi + lx.i1);
-    float v = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
-    Io<T>::st(out + n_ * out_bs + c_ * out_ps + (long)y * Wo + x, v);
+    const T* p0 = in + n_ * in_bs + c_ * in_ps + (long)ly.i0 * Wi;
+    const T* p1 = in + n_ * in_bs + c_ * in_ps + (long)ly.i1 * Wi;
+    float v[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+      const Lerp lx = ge_lerp(x + k, Wi, sx, align);
+      const float v00 = Io<T>::ld(p0 + lx.i0), v01 = Io<T>::ld(p0 + lx.i1);
+      const float v10 = Io<T>::ld(p1 + lx.i0), v11 = Io<T>::ld(p1 + lx.i1);
+      v[k] = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
+    }
+    T* o = out + n_ * out_bs + c_ * out_ps + (long)y * Wo + x;
+    if (VEC) V8<T>::st(o, v);
+    else Io<T>::st(o, v[0]);
   }
 }
 
@@ -43,7 +55,7 @@ __device__ __forceinline__ void cand_range(int X, int in, int out, float scale, 
   if (hi > out - 1) hi = out - 1;
 }
 
-#define GE_MAXC 12  // candidate taps per dimension kept in registers (enough for >= 0.2x scaling)
+#define GE_MAXC 8   // candidate taps per dimension kept in registers (up-sampling factors <= 2.5; wider ranges take the loop)
 
 template <typename T>
 __global__ void __launch_bounds__(256) bilinear_bwd_k(const T* __restrict__ gout, T* __restrict__ gin, int NC,
@@ -62,17 +74,39 @@ __global__ void __launch_bounds__(256) bilinear_bwd_k(const T* __restrict__ gout
     const long n_ = nc / C, c_ = nc - n_ * C;
     const T* g = gout + n_ * gout_bs + c_ * gout_ps;
     float acc = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      Lerp ly = ge_lerp(oy, Hi, sy, align);
-      float wy = (ly.i0 == Y ? ly.w0 : 0.f) + (ly.i1 == Y ? ly.w1 : 0.f);
-      if (wy == 0.f) continue;
-      float row = 0.f;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        Lerp lx = ge_lerp(ox, Wi, sx, align);
-        float wx = (lx.i0 == X ? lx.w0 : 0.f) + (lx.i1 == X ? lx.w1 : 0.f);
-        if (wx != 0.f) row += wx * Io<T>::ld(g + (long)oy * Wo + ox);
+    if (xhi - xlo < GE_MAXC) {
+      // the column weights do not depend on the row: evaluate them once (<= GE_MAXC candidates in registers)
+      float wxs[GE_MAXC];
+#pragma unroll
+      for (int k = 0; k < GE_MAXC; ++k) {
+        const int ox = min(xlo + k, Wo - 1);
+        const Lerp lx = ge_lerp(ox, Wi, sx, align);
+        wxs[k] = xlo + k <= xhi ? (lx.i0 == X ? lx.w0 : 0.f) + (lx.i1 == X ? lx.w1 : 0.f) : 0.f;
       }
-      acc += wy * row;
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const Lerp ly = ge_lerp(oy, Hi, sy, align);
+        const float wy = (ly.i0 == Y ? ly.w0 : 0.f) + (ly.i1 == Y ? ly.w1 : 0.f);
+        if (wy == 0.f) continue;
+        const T* gr = g + (long)oy * Wo + xlo;
+        float row = 0.f;
+#pragma unroll
+        for (int k = 0; k < GE_MAXC; ++k)
+          if (wxs[k] != 0.f) row += wxs[k] * Io<T>::ld(gr + k);
+        acc += wy * row;
+      }
+    } else {
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        Lerp ly = ge_lerp(oy, Hi, sy, align);
+        float wy = (ly.i0 == Y ? ly.w0 : 0.f) + (ly.i1 == Y ? ly.w1 : 0.f);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          Lerp lx = ge_lerp(ox, Wi, sx, align);
+          float wx = (lx.i0 == X ? lx.w0 : 0.f) + (lx.i1 == X ? lx.w1 : 0.f);
+          if (wx != 0.f) row += wx * Io<T>::ld(g + (long)oy * Wo + ox);
+        }
+        acc += wy * row;
+      }
     }
     Io<T>::st(gin + n_ * gin_bs + c_ * gin_ps + (long)Y * Wi + X, acc);
   }
@@ -83,7 +117,11 @@ static int bilinear_fwd_launch(const void* in, void* out, int N, int C, int Hi, 
                                long ibs, long ips, long obs, long ops, hipStream_t s) {
   long total = (long)N * C * Ho * Wo;
   if (total == 0) return GE_OK;
-  bilinear_fwd_k<T><<<ge_blocks(total, 256, 65536), 256, 0, s>>>((const T*)in, (T*)out, N * C, Hi, Wi, Ho, Wo, align, C, ibs, ips, obs, ops);
+  const bool vec = Wo % V8<T>::N == 0 && obs % V8<T>::N == 0 && ops % V8<T>::N == 0 && (((uintptr_t)out) & 15) == 0;
+  if (vec)
+    bilinear_fwd_k<T, true><<<ge_blocks(total / V8<T>::N, 256, 65536), 256, 0, s>>>((const T*)in, (T*)out, N * C, Hi, Wi, Ho, Wo, align, C, ibs, ips, obs, ops);
+  else
+    bilinear_fwd_k<T, false><<<ge_blocks(total, 256, 65536), 256, 0, s>>>((const T*)in, (T*)out, N * C, Hi, Wi, Ho, Wo, align, C, ibs, ips, obs, ops);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
