@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, M
                                                   long n_groups, int Nv, int Nq, int nH, int L, int P) {
   constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // lanes per (b,q,head) group: 16 (fp32) / 8 (bf16)
   const int c0 = (threadIdx.x % G) * CPL;
+  const int nh64 = nH * 64;                                 // 32-bit element offsets inside one image (launcher: Nv * nH * 64 < 2^31)
   const long grp0 = msda_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x / G) + (threadIdx.x / G);
   const long gstride = (long)gridDim.x * (blockDim.x / G);
   for (long grp = grp0; grp < n_groups; grp += gstride) {   // grp = (b*Nq + q)*nH + head (one trip: the grid covers all)
@@ -132,10 +133,10 @@ __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, M
         const float wxa = x0 >= 0 ? 1.f - ax : 0.f, wxb = x0 + 1 < Wl ? ax : 0.f;
         const float wya = y0 >= 0 ? 1.f - ay : 0.f, wyb = y0 + 1 < Hl ? ay : 0.f;
         float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
-        VecL<T>::ld(vl + ((long)ya * Wl + xa) * nH * 64, v00);
-        VecL<T>::ld(vl + ((long)ya * Wl + xb) * nH * 64, v01);
-        VecL<T>::ld(vl + ((long)yb * Wl + xa) * nH * 64, v10);
-        VecL<T>::ld(vl + ((long)yb * Wl + xb) * nH * 64, v11);
+        VecL<T>::ld(vl + (ya * Wl + xa) * nh64, v00);
+        VecL<T>::ld(vl + (ya * Wl + xb) * nh64, v01);
+        VecL<T>::ld(vl + (yb * Wl + xa) * nh64, v10);
+        VecL<T>::ld(vl + (yb * Wl + xb) * nh64, v11);
         const float w00 = wya * wxa * wgt, w01 = wya * wxb * wgt, w10 = wyb * wxa * wgt, w11 = wyb * wxb * wgt;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) acc[i] += w00 * v00[i] + w01 * v01[i] + w10 * v10[i] + w11 * v11[i];
@@ -309,6 +310,7 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
   constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // 16-byte loads: 16 lanes (fp32) / 8 lanes (bf16) per group
   const int sub = threadIdx.x % G;
   const int c0 = sub * CPL;
+  const int nh64 = nH * 64;
   const long grp0 = msda_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x / G) + (threadIdx.x / G);
   const long gstride = (long)gridDim.x * (blockDim.x / G);
   const long iters = (n_groups + gstride - 1) / gstride;          // wave-uniform trip count: the shuffles need all lanes
@@ -338,10 +340,10 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
       const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);                           \
       const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);                           \
       const bool k_xa = in && x0 >= 0, k_xb = in && x0 + 1 < Wl, k_ya = y0 >= 0, k_yb = y0 + 1 < Hl;      \
-      const lw_raw_t r00 = *(const lw_raw_t*)(vl + ((long)ya * Wl + xa) * nH * 64);                        \
-      const lw_raw_t r01 = *(const lw_raw_t*)(vl + ((long)ya * Wl + xb) * nH * 64);                        \
-      const lw_raw_t r10 = *(const lw_raw_t*)(vl + ((long)yb * Wl + xa) * nH * 64);                        \
-      const lw_raw_t r11 = *(const lw_raw_t*)(vl + ((long)yb * Wl + xb) * nH * 64);                        \
+      const lw_raw_t r00 = *(const lw_raw_t*)(vl + (ya * Wl + xa) * nh64);                        \
+      const lw_raw_t r01 = *(const lw_raw_t*)(vl + (ya * Wl + xb) * nh64);                        \
+      const lw_raw_t r10 = *(const lw_raw_t*)(vl + (yb * Wl + xa) * nh64);                        \
+      const lw_raw_t r11 = *(const lw_raw_t*)(vl + (yb * Wl + xb) * nh64);                        \
       float d00 = RowDot<T>::dot(go, r00), d01 = RowDot<T>::dot(go, r01);                                 \
       float d10 = RowDot<T>::dot(go, r10), d11 = RowDot<T>::dot(go, r11);                                 \
       d00 = (k_ya && k_xa) ? d00 : 0.f; d01 = (k_ya && k_xb) ? d01 : 0.f;   /* selects: a masked corner may hold anything */ \
@@ -792,7 +794,7 @@ extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const float
   if (e) return e;
   const long n_groups = (long)B * Nq * nH;
   if (n_groups == 0) return GE_OK;
-  if ((n_groups + 15) / 16 > (1L << 30)) return GE_ERR_UNSUPPORTED;
+  if ((n_groups + 15) / 16 > (1L << 30) || (long)Nv * nH * 64 >= (1L << 31)) return GE_ERR_UNSUPPORTED;
   const unsigned blocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
   if (dtype == GE_F32)
     msda_fwd_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)value, lv, loc, attw, (float*)out, n_groups, Nv, Nq, nH, L, P);

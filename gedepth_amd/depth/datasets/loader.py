@@ -42,14 +42,17 @@ class SyntheticKITTI(torch.utils.data.Dataset):
 
     def __init__(self, length=64, height=352, width=1120, adaptive=True, seed=1234):
         self.length, self.h, self.w, self.adaptive, self.seed = length, height, width, adaptive, seed
+        self._cache = {}                          # generating a sample costs ~0.25 s of host time: do it once per index
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, i):
-        from .synthetic import synthetic_batch
-        b = synthetic_batch(1, self.h, self.w, seed=self.seed + i)
-        out = dict(img=b['img'][0], img_metas=b['img_metas'][0], depth_gt=b['depth_gt'][0])
-        if self.adaptive:
-            out['pe_k_gt'] = b['pe_k_gt'][0]
-        return out
+        if i not in self._cache:
+            from .synthetic import synthetic_batch
+            b = synthetic_batch(1, self.h, self.w, seed=self.seed + i)
+            out = dict(img=b['img'][0], img_metas=b['img_metas'][0], depth_gt=b['depth_gt'][0])
+            if self.adaptive:
+                out['pe_k_gt'] = b['pe_k_gt'][0]
+            self._cache[i] = out
+        return dict(self._cache[i])
