@@ -34,7 +34,8 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu=0, dist=True, shu
     rank, world = get_dist_info()
     sampler = DistributedSampler(dataset, world, rank, shuffle=shuffle, seed=seed or 0) if dist else None
     return DataLoader(dataset, batch_size=samples_per_gpu, sampler=sampler, shuffle=(shuffle and sampler is None),
-                      num_workers=workers_per_gpu, collate_fn=collate, pin_memory=pin_memory, drop_last=drop_last)
+                      num_workers=workers_per_gpu, collate_fn=collate, pin_memory=pin_memory, drop_last=drop_last,
+                      persistent_workers=workers_per_gpu > 0)      # the iter-based runner re-enters the loader every epoch
 
 
 class SyntheticKITTI(torch.utils.data.Dataset):

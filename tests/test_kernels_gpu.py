@@ -294,7 +294,8 @@ def test_bilinear_bwd_is_deterministic_and_adjoint(dev):
     bilinear_resize(x, (176, 560), True).backward(g)
     assert torch.equal(g1, x.grad)
     lhs, rhs = (y.detach().double() * g.double()).sum(), (x.detach().double() * g1.double()).sum()
-    assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+    # fp32 rounding of the 6.3 M products: compare against the Cauchy-Schwarz scale, not against the (random-sign) sum itself
+    assert abs(lhs - rhs) <= 1e-6 * y.detach().double().norm() * g.double().norm()
 
 
 # ====================================================================== ground embedding
