@@ -253,3 +253,261 @@ extern "C" int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int 
   if (x_dtype == GE_BF16 && y_dtype == GE_F32) return ln_bwd_launch<bf16_t, float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s);
   return GE_ERR_UNSUPPORTED;
 }
+
+// ============================================================================ BatchNorm2d (training) + ReLU, NCHW
+// conv -> BN -> ReLU of mmcv ConvModule (necks/hahi.py:150-166 lateral / proj / fusion convs, depthformer_swin.py:1127-1139
+// stem).  MIOpen's spatial BN plus ATen's clamp / threshold_backward make four kernels and ~10 passes over the map; here:
+//   forward : bn_stats_k (one read: per-channel sum, sum of squares; fp32 per thread, fp64 across threads) ->
+//             bn_finalize_k (mean, rstd, running statistics, per-channel scale / shift) -> bn_apply_k (read x, write y)
+//   backward: bn_bwd_stats_k (read dy, y, x: sum g, sum g * xhat with g = dy * relu'(y)) -> bn_bwd_finalize_k ->
+//             bn_bwd_apply_k (read dy, y, x, write dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)))
+// HBM-bound streaming kernels, 16-byte vectors, one (n, c) plane per blockIdx.y like bias_act.
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) bn_stats_k(const T* __restrict__ x, double* __restrict__ ws, int C, long HW) {
+  const long plane = blockIdx.y;
+  const T* p = x + plane * HW;
+  constexpr int VN = V8<T>::N;
+  float s = 0.f, ss = 0.f;
+  if (VEC) {
+    const long nv = HW / VN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float v[VN];
+      V8<T>::ld(p + i * VN, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) { s += v[k]; ss += v[k] * v[k]; }
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+      const float v = Io<T>::ld(p + i);
+      s += v; ss += v * v;
+    }
+  }
+  double ds = s, dss = ss;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dss += __shfl_xor(dss, o, 64); }
+  __shared__ double sm[8];
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = ds; sm[4 + (threadIdx.x >> 6)] = dss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int c = (int)(plane % C);
+    atomicAdd(&ws[c], sm[0] + sm[1] + sm[2] + sm[3]);
+    atomicAdd(&ws[C + c], sm[4] + sm[5] + sm[6] + sm[7]);
+  }
+}
+
+// ws: [0,C) sum, [C,2C) sum of squares (in) ; coef: [0,C) scale = gamma * rstd, [C,2C) shift = beta - mean * scale (out)
+__global__ void __launch_bounds__(256) bn_finalize_k(const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float* __restrict__ coef, int C, double n,
+                                                     float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = ws[c] / n;
+  double var = ws[C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean;
+  save_rstd[c] = rstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+  const float a = gamma[c] * rstd;
+  coef[c] = a;
+  coef[C + c] = beta[c] - (float)mean * a;
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) bn_apply_k(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y,
+                                                  int C, long HW, float slope) {
+  const long plane = blockIdx.y;
+  const int c = (int)(plane % C);
+  const float a = coef[c], b = coef[C + c];
+  const T* p = x + plane * HW;
+  T* q = y + plane * HW;
+  constexpr int VN = V8<T>::N;
+  if (VEC) {
+    const long nv = HW / VN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float v[VN];
+      V8<T>::ld(p + i * VN, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) { const float t = v[k] * a + b; v[k] = t > 0.f ? t : t * slope; }
+      V8<T>::st(q + i * VN, v);
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+      const float t = Io<T>::ld(p + i) * a + b;
+      Io<T>::st(q + i, t > 0.f ? t : t * slope);
+    }
+  }
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) bn_bwd_stats_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                      const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                      double* __restrict__ ws, int C, long HW, float slope) {
+  const long plane = blockIdx.y;
+  const int c = (int)(plane % C);
+  const float mu = save_mean[c], rs = save_rstd[c];
+  const T* gp = dy + plane * HW;
+  const T* yp = y + plane * HW;
+  const T* xp = x + plane * HW;
+  constexpr int VN = V8<T>::N;
+  float s1 = 0.f, s2 = 0.f;
+  if (VEC) {
+    const long nv = HW / VN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float g[VN], yv[VN], xv[VN];
+      V8<T>::ld(gp + i * VN, g);
+      V8<T>::ld(yp + i * VN, yv);
+      V8<T>::ld(xp + i * VN, xv);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) {
+        const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
+        s1 += gg;
+        s2 += gg * ((xv[k] - mu) * rs);
+      }
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+      float gg = Io<T>::ld(gp + i);
+      gg = Io<T>::ld(yp + i) > 0.f ? gg : gg * slope;
+      s1 += gg;
+      s2 += gg * ((Io<T>::ld(xp + i) - mu) * rs);
+    }
+  }
+  double d1 = s1, d2 = s2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d1 += __shfl_xor(d1, o, 64); d2 += __shfl_xor(d2, o, 64); }
+  __shared__ double sm[8];
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = d1; sm[4 + (threadIdx.x >> 6)] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[c], sm[0] + sm[1] + sm[2] + sm[3]);
+    atomicAdd(&ws[C + c], sm[4] + sm[5] + sm[6] + sm[7]);
+  }
+}
+
+// ws: sum g, sum g * xhat -> dbeta, dgamma and the per-channel terms of dx: coef = {gamma * rstd, mean(g), mean(g * xhat)}
+__global__ void __launch_bounds__(256) bn_bwd_finalize_k(const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                         const float* __restrict__ save_rstd, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, float* __restrict__ coef, int C, double n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)ws[c];
+  dgamma[c] = (float)ws[C + c];
+  coef[c] = gamma[c] * save_rstd[c];
+  coef[C + c] = (float)(ws[c] / n);
+  coef[2 * C + c] = (float)(ws[C + c] / n);
+}
+
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                      const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                      const float* __restrict__ coef, T* __restrict__ dx, int C, long HW,
+                                                      float slope) {
+  const long plane = blockIdx.y;
+  const int c = (int)(plane % C);
+  const float mu = save_mean[c], rs = save_rstd[c], a = coef[c], m1 = coef[C + c], m2 = coef[2 * C + c];
+  const T* gp = dy + plane * HW;
+  const T* yp = y + plane * HW;
+  const T* xp = x + plane * HW;
+  T* dp = dx + plane * HW;
+  constexpr int VN = V8<T>::N;
+  if (VEC) {
+    const long nv = HW / VN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float g[VN], yv[VN], xv[VN];
+      V8<T>::ld(gp + i * VN, g);
+      V8<T>::ld(yp + i * VN, yv);
+      V8<T>::ld(xp + i * VN, xv);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) {
+        const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
+        g[k] = a * (gg - m1 - ((xv[k] - mu) * rs) * m2);
+      }
+      V8<T>::st(dp + i * VN, g);
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+      float gg = Io<T>::ld(gp + i);
+      gg = Io<T>::ld(yp + i) > 0.f ? gg : gg * slope;
+      Io<T>::st(dp + i, a * (gg - m1 - ((Io<T>::ld(xp + i) - mu) * rs) * m2));
+    }
+  }
+}
+
+static inline dim3 bn_grid(int N, int C, long HW, int vn, bool vec) {
+  const long per_plane = vec ? HW / vn : HW;
+  long gx = (per_plane + 256 * 4 - 1) / (256 * 4);
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  return dim3((unsigned)gx, (unsigned)(N * C));
+}
+static inline bool bn_vec(long HW, int vn, const void* a, const void* b, const void* c, const void* d) {
+  return HW % vn == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
+extern "C" size_t ge_bn_workspace(int C) { return (size_t)C * (2 * sizeof(double) + 3 * sizeof(float)); }
+
+template <typename T>
+static int bn_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                         float* running_mean, float* running_var, void* workspace, int N, int C, long HW, float eps,
+                         float momentum, float slope, hipStream_t s) {
+  double* ws = (double*)workspace;
+  float* coef = (float*)(ws + 2 * C);
+  hipError_t he = hipMemsetAsync(ws, 0, (size_t)C * 2 * sizeof(double), s);
+  if (he != hipSuccess) return (int)he;
+  const bool vec = bn_vec(HW, V8<T>::N, x, y, nullptr, nullptr);
+  const dim3 grid = bn_grid(N, C, HW, V8<T>::N, vec);
+  if (vec) bn_stats_k<T, true><<<grid, 256, 0, s>>>((const T*)x, ws, C, HW);
+  else bn_stats_k<T, false><<<grid, 256, 0, s>>>((const T*)x, ws, C, HW);
+  GE_LAUNCH_CHECK();
+  bn_finalize_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, beta, save_mean, save_rstd, running_mean, running_var, coef, C,
+                                               (double)N * (double)HW, eps, momentum);
+  GE_LAUNCH_CHECK();
+  if (vec) bn_apply_k<T, true><<<grid, 256, 0, s>>>((const T*)x, coef, (T*)y, C, HW, slope);
+  else bn_apply_k<T, false><<<grid, 256, 0, s>>>((const T*)x, coef, (T*)y, C, HW, slope);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+template <typename T>
+static int bn_bwd_launch(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                         const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, int N, int C, long HW,
+                         float slope, hipStream_t s) {
+  double* ws = (double*)workspace;
+  float* coef = (float*)(ws + 2 * C);
+  hipError_t he = hipMemsetAsync(ws, 0, (size_t)C * 2 * sizeof(double), s);
+  if (he != hipSuccess) return (int)he;
+  const bool vec = bn_vec(HW, V8<T>::N, dy, y, x, dx);
+  const dim3 grid = bn_grid(N, C, HW, V8<T>::N, vec);
+  if (vec) bn_bwd_stats_k<T, true><<<grid, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, ws, C, HW, slope);
+  else bn_bwd_stats_k<T, false><<<grid, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, ws, C, HW, slope);
+  GE_LAUNCH_CHECK();
+  bn_bwd_finalize_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, save_rstd, dgamma, dbeta, coef, C, (double)N * (double)HW);
+  GE_LAUNCH_CHECK();
+  if (vec) bn_bwd_apply_k<T, true><<<grid, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, coef, (T*)dx, C, HW, slope);
+  else bn_bwd_apply_k<T, false><<<grid, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, coef, (T*)dx, C, HW, slope);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+extern "C" int ge_bn_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                             float* running_mean, float* running_var, void* workspace, int N, int C, long HW, float eps,
+                             float momentum, float slope, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || N <= 0 || C <= 0 || HW <= 0) return GE_ERR_BAD_ARG;
+  if ((long)N * C > 2147483647L) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bn_fwd_launch<float>(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, workspace, N, C, HW, eps, momentum, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bn_fwd_launch<bf16_t>(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, workspace, N, C, HW, eps, momentum, slope, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+extern "C" int ge_bn_act_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                             const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, int N, int C, long HW,
+                             float slope, int dtype, void* stream) {
+  if (!dy || !y || !x || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || N <= 0 || C <= 0 || HW <= 0)
+    return GE_ERR_BAD_ARG;
+  if ((long)N * C > 2147483647L) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bn_bwd_launch<float>(dy, y, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, workspace, N, C, HW, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bn_bwd_launch<bf16_t>(dy, y, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, workspace, N, C, HW, slope, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}

@@ -254,7 +254,13 @@ class DepthFormerSwin(BaseModule):
 
     # ------------------------------------------------------------------ forward
     def conv_stem(self, x):
-        return F.relu(getattr(self, self._stem_norm_name)(self.conv1(x)), inplace=True)
+        bn = getattr(self, self._stem_norm_name)
+        y = self.conv1(x)
+        if (y.is_cuda and type(bn) is nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats
+                and bn.momentum is not None):
+            from ....kernels import bn_act
+            return bn_act(y, bn, 0.0)                         # training-mode BN + ReLU in two streaming passes
+        return F.relu(bn(y), inplace=True)
 
     def forward(self, x_ori):
         outs = [self.conv_stem(x_ori[:, 0:3] if self.USEPE else x_ori)]

@@ -35,6 +35,9 @@ SIGNATURES = {
     'ge_bilinear_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_layernorm_fwd': (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _f, _vp]),
     'ge_layernorm_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
+    'ge_bn_workspace': (_sz, [_i]),
+    'ge_bn_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _f, _f, _f, _i, _vp]),
+    'ge_bn_act_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp]),
     'ge_bias_act_fwd': (_i, [_vp, _vp, _i, _i, _l, _f, _i, _vp]),
     'ge_bias_act_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _l, _f, _i, _vp]),
     'ge_ground_embed_fwd': (_i, [_vp, _vp, _vp, _l, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -418,6 +418,48 @@ def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype or x.dtype)
 
 
+# ------------------------------------------------------------------ batch norm (training) + ReLU
+class _BNAct(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, slope):
+        x = _c(x)
+        N, C, H, W = x.shape
+        w, b = _c(weight.detach().to(_f32)), _c(bias.detach().to(_f32))
+        y = torch.empty_like(x)
+        stats = torch.empty(2, C, device=x.device, dtype=_f32)
+        ws = torch.empty(int(hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
+        PROFILER.run(f'bn_act_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 3 * x.numel() * _es(x), lambda: hip.check(
+            hip.lib().ge_bn_act_fwd(hip.ptr(x, name='x'), hip.ptr(w), hip.ptr(b), hip.ptr(y), hip.ptr(stats[0]), hip.ptr(stats[1]),
+                                    hip.ptr(running_mean, _f32), hip.ptr(running_var, _f32), hip.ptr(ws), N, C, H * W, eps,
+                                    momentum, slope, hip.dtype_code(x), hip.stream()), 'ge_bn_act_fwd'))
+        ctx.save_for_backward(x, y, w, stats)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w, stats = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = _c(dy.to(x.dtype))
+        dx = torch.empty_like(x)
+        dwb = torch.empty(2, C, device=x.device, dtype=_f32)
+        ws = torch.empty(int(hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
+        PROFILER.run(f'bn_act_bwd[{N}x{C}x{H}x{W} {_tag(x)}]', 7 * x.numel() * _es(x), lambda: hip.check(
+            hip.lib().ge_bn_act_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(x), hip.ptr(w), hip.ptr(stats[0]), hip.ptr(stats[1]), hip.ptr(dx),
+                                    hip.ptr(dwb[0]), hip.ptr(dwb[1]), hip.ptr(ws), N, C, H * W, ctx.slope, hip.dtype_code(x),
+                                    hip.stream()), 'ge_bn_act_bwd'))
+        return dx, dwb[0], dwb[1], None, None, None, None, None
+
+
+def bn_act(x, bn, slope=0.0):
+    """Training-mode ``nn.BatchNorm2d`` followed by leaky-ReLU(slope) (0 = ReLU, 1 = none) on an NCHW map; updates the
+    module's running statistics and ``num_batches_tracked`` like ``F.batch_norm``."""
+    y = _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), float(slope))
+    bn.num_batches_tracked.add_(1)
+    return y
+
+
 # ------------------------------------------------------------------------- bias + activation
 class _BiasAct(torch.autograd.Function):
 

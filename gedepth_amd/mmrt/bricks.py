@@ -225,10 +225,34 @@ class ConvModule(nn.Module):
             return 0.0
         return None
 
+    def _fused_bn_slope(self):
+        """leaky slope when norm + activation can run as the fused training-mode BatchNorm kernels, else None."""
+        bn = self.norm
+        if (type(bn) is not nn.BatchNorm2d or not bn.training or not bn.affine or not bn.track_running_stats
+                or bn.momentum is None or self.conv.bias is not None):
+            return None
+        if not self.with_activation:
+            return 1.0
+        if isinstance(self.activate, nn.ReLU):
+            return 0.0
+        if isinstance(self.activate, nn.LeakyReLU):
+            return float(self.activate.negative_slope)
+        return None
+
     def forward(self, x):
         slope = self._fused_slope() if x.is_cuda else None
         if slope is not None:
             return conv_bias_act(self.conv, x, slope)
+        if x.is_cuda and self.with_norm:
+            slope = self._fused_bn_slope()
+            if slope is not None:
+                from .. import kernels
+                y = self.conv(x)
+                if y.dtype in (torch.float32, torch.bfloat16):
+                    return kernels.bn_act(y, self.norm, slope)
+                x = y
+                x = self.norm(x)
+                return self.activate(x) if self.with_activation else x
         x = self.conv(x)
         if self.with_norm:
             x = self.norm(x)

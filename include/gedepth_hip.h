@@ -150,6 +150,22 @@ int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int x_dtype, co
                      const float* rstd, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d in training mode + (leaky-)ReLU, NCHW: the norm -> act tail of mmcv ConvModule (necks/hahi.py:150-166,
+ * depthformer_swin.py:1127-1139).  y = act((x - mean_c) * rstd_c * gamma_c + beta_c) with batch statistics over (N, H, W)
+ * (biased variance), running_mean / running_var updated with `momentum` (unbiased variance), save_mean / save_rstd
+ * returned for the backward pass.  Backward: g = dy * act'(y); dbeta = sum g, dgamma = sum g * xhat,
+ * dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)).  x / y / dy / dx in `dtype`, everything per-channel f32.
+ * `workspace`: ge_bn_workspace(C) bytes of device scratch (the entry points zero what they need).
+ */
+size_t ge_bn_workspace(int C);
+int ge_bn_act_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                  float* running_mean, float* running_var, void* workspace, int N, int C, long HW, float eps,
+                  float momentum, float slope, int dtype, void* stream);
+int ge_bn_act_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                  const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, int N, int C, long HW,
+                  float slope, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bias + activation after a bias-free convolution, NCHW, in place: x = act(x + bias[c]) with
  * act = leaky-relu(slope) (slope 0 = ReLU, 1 = identity).  Replaces the broadcast bias add + activation kernels of
  * mmcv ConvModule without norm (decode_heads/densedepth_head.py:14-27) and of the PE-neck convs

@@ -556,6 +556,71 @@ def test_layer_norm_module_follows_autocast(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 5, 7, 9), (3, 16, 12, 16), (2, 64, 24, 40)])
+@pytest.mark.parametrize('slope', [0.0, 1.0])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_bn_act_training(dev, shape, slope, dtype):
+    """nn.BatchNorm2d (training) + ReLU of mmcv ConvModule: output, running statistics, num_batches_tracked and the three
+    gradients against F.batch_norm + relu in fp32 on the same stored values."""
+    from gedepth_amd.kernels import bn_act
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = gen(31)
+    N, C, H, W = shape
+    x = (torch.randn(*shape, generator=g) * 1.5 + 0.3).to(td)
+    go = torch.randn(*shape, generator=g).to(td)
+    ref_bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref_bn.weight.copy_(torch.randn(C, generator=g)); ref_bn.bias.copy_(torch.randn(C, generator=g))
+        ref_bn.running_mean.copy_(torch.randn(C, generator=g)); ref_bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    import copy
+    bn = copy.deepcopy(ref_bn).to(dev)
+    xc = x.float().clone().requires_grad_(True)
+    t = ref_bn(xc)
+    ref = t if slope == 1.0 else F.relu(t)
+    ref.backward(go.float())
+    xg = x.to(dev).requires_grad_(True)
+    out = bn_act(xg, bn, slope)
+    out.backward(go.to(dev))
+    tol = dict(rtol=2 ** -7, atol=2 ** -7) if dtype == 'bf16' else dict(rtol=2e-5, atol=2e-5)
+    close(out.float(), ref, what='y', **tol)
+    close(bn.running_mean, ref_bn.running_mean, rtol=1e-5, atol=1e-6, what='running_mean')
+    close(bn.running_var, ref_bn.running_var, rtol=1e-5, atol=1e-6, what='running_var')
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    if dtype == 'bf16':
+        # a bf16-rounded y flips relu'(y) only where |y| is at rounding level: compare in norm
+        assert (xg.grad.float().cpu() - xc.grad).norm() <= 2e-2 * xc.grad.norm()
+        assert (bn.weight.grad.cpu() - ref_bn.weight.grad).norm() <= 2e-2 * ref_bn.weight.grad.norm()
+        assert (bn.bias.grad.cpu() - ref_bn.bias.grad).norm() <= 2e-2 * ref_bn.bias.grad.norm()
+    else:
+        close_scaled(xg.grad, xc.grad, what='dx')
+        close_scaled(bn.weight.grad, ref_bn.weight.grad, what='dgamma')
+        close_scaled(bn.bias.grad, ref_bn.bias.grad, what='dbeta')
+
+
+@pytest.mark.gpu
+def test_conv_module_bn_relu_fused_matches_unfused(dev):
+    from gedepth_amd.mmrt.bricks import ConvModule
+    torch.manual_seed(0)
+    m = ConvModule(8, 16, 3, padding=1, norm_cfg=dict(type='BN', requires_grad=True), act_cfg=dict(type='ReLU')).to(dev).train()
+    x = torch.randn(2, 8, 24, 40, device=dev)
+    go = torch.randn(2, 16, 24, 40, device=dev)
+    out = m(x)
+    out.backward(go)
+    gw, gg = m.conv.weight.grad.clone(), m.bn.weight.grad.clone()
+    rm = m.bn.running_mean.clone()
+    m.zero_grad(); m.bn.reset_running_stats()
+    ref = F.relu(F.batch_norm(F.conv2d(x, m.conv.weight, None, padding=1), m.bn.running_mean, m.bn.running_var, m.bn.weight,
+                              m.bn.bias, True, 0.1, 1e-5))
+    ref.backward(go)
+    close(out, ref, rtol=1e-4, atol=1e-4, what='y')
+    close_scaled(gw, m.conv.weight.grad, what='d conv weight')
+    close_scaled(gg, m.bn.weight.grad, what='dgamma')
+    close(rm, m.bn.running_mean, rtol=1e-5, atol=1e-6, what='running_mean')
+    m.eval()
+    assert torch.allclose(m(x), F.relu(m.bn(m.conv(x))))                      # eval mode: the library path
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 5, 7, 9), (2, 16, 12, 16), (1, 3, 1, 1)])
 @pytest.mark.parametrize('slope', [1.0, 0.0, 0.01])
 def test_bias_act_fp32(dev, shape, slope):
