@@ -202,3 +202,85 @@ extern "C" int ge_map_from_tokens(const void* tok, long tok_bs, const void* res,
   if (dtype == GE_BF16) return map_from_tokens_launch<bf16_t>(tok, tok_bs, res, res_bs, map, map_bs, B, C, N, p_drop, seed, ge_stream(stream));
   return GE_ERR_UNSUPPORTED;
 }
+
+// ============================================================================ residual + stochastic depth
+// out[b, i] = identity[b, i] + branch[b, i] * scale[b]      (scale[b] = Bernoulli(keep) / keep per sample)
+// = `identity + DropPath(branch)` of the Swin blocks (depthformer_swin.py:461-472 via mmcv DropPath / FFN): ATen runs a
+// divide, a multiply and an add over the token tensor; this is one pass, mixed precision (fp32 residual stream + bf16
+// branch in stage 0).  Backward of the branch: d_branch = d_out * scale[b] (ge_scale_rows); the identity gradient is d_out.
+template <typename T> struct E8;       // 8 consecutive elements <-> 8 floats
+template <> struct E8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float v[8]) { V8<float>::ld(p, v); V8<float>::ld(p + 4, v + 4); }
+  static __device__ __forceinline__ void st(float* p, const float v[8]) { V8<float>::st(p, v); V8<float>::st(p + 4, v + 4); }
+};
+template <> struct E8<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) { V8<bf16_t>::ld(p, v); }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) { V8<bf16_t>::st(p, v); }
+};
+
+// HAS_ID = false: out = branch * scale (the backward pass)
+template <typename TI, typename TB, typename TO, bool HAS_ID, bool VEC>
+__global__ void __launch_bounds__(256) scale_add_k(const TI* __restrict__ identity, const TB* __restrict__ branch,
+                                                   const float* __restrict__ scale, TO* __restrict__ out, long per_sample) {
+  const int b = blockIdx.y;
+  const float sc = scale[b];
+  const long base = (long)b * per_sample;
+  if (VEC) {
+    const long nv = per_sample / 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float x[8], y[8];
+      E8<TB>::ld(branch + base + i * 8, y);
+      if (HAS_ID) {
+        E8<TI>::ld(identity + base + i * 8, x);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = x[k] + y[k] * sc;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = y[k] * sc;
+      }
+      E8<TO>::st(out + base + i * 8, y);
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (long)gridDim.x * blockDim.x) {
+      const float y = Io<TB>::ld(branch + base + i) * sc;
+      Io<TO>::st(out + base + i, HAS_ID ? Io<TI>::ld(identity + base + i) + y : y);
+    }
+  }
+}
+
+template <typename TI, typename TB, typename TO, bool HAS_ID>
+static int scale_add_launch(const void* identity, const void* branch, const float* scale, void* out, int B, long per_sample,
+                            hipStream_t s) {
+  const bool vec = per_sample % 8 == 0 && al16(branch) && al16(out) && (!HAS_ID || al16(identity));
+  long gx = ((vec ? per_sample / 8 : per_sample) + 256 * 4 - 1) / (256 * 4);
+  if (gx < 1) gx = 1;
+  if (gx > 4096) gx = 4096;
+  dim3 grid((unsigned)gx, (unsigned)B);
+  if (vec) scale_add_k<TI, TB, TO, HAS_ID, true><<<grid, 256, 0, s>>>((const TI*)identity, (const TB*)branch, scale, (TO*)out, per_sample);
+  else scale_add_k<TI, TB, TO, HAS_ID, false><<<grid, 256, 0, s>>>((const TI*)identity, (const TB*)branch, scale, (TO*)out, per_sample);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+extern "C" int ge_residual_scale_add(const void* identity, int id_dtype, const void* branch, int br_dtype, const float* scale,
+                                     void* out, int B, long per_sample, void* stream) {
+  if (!identity || !branch || !scale || !out || B < 0 || B > 65535 || per_sample < 0) return GE_ERR_BAD_ARG;
+  if ((long)B * per_sample == 0) return GE_OK;
+  hipStream_t s = ge_stream(stream);
+  if (id_dtype == GE_F32 && br_dtype == GE_F32) return scale_add_launch<float, float, float, true>(identity, branch, scale, out, B, per_sample, s);
+  if (id_dtype == GE_F32 && br_dtype == GE_BF16) return scale_add_launch<float, bf16_t, float, true>(identity, branch, scale, out, B, per_sample, s);
+  if (id_dtype == GE_BF16 && br_dtype == GE_BF16) return scale_add_launch<bf16_t, bf16_t, bf16_t, true>(identity, branch, scale, out, B, per_sample, s);
+  return GE_ERR_UNSUPPORTED;
+}
+
+extern "C" int ge_scale_rows(const void* x, int x_dtype, const float* scale, void* out, int out_dtype, int B, long per_sample,
+                             void* stream) {
+  if (!x || !scale || !out || B < 0 || B > 65535 || per_sample < 0) return GE_ERR_BAD_ARG;
+  if ((long)B * per_sample == 0) return GE_OK;
+  hipStream_t s = ge_stream(stream);
+  if (x_dtype == GE_F32 && out_dtype == GE_F32) return scale_add_launch<float, float, float, false>(nullptr, x, scale, out, B, per_sample, s);
+  if (x_dtype == GE_F32 && out_dtype == GE_BF16) return scale_add_launch<float, float, bf16_t, false>(nullptr, x, scale, out, B, per_sample, s);
+  if (x_dtype == GE_BF16 && out_dtype == GE_BF16) return scale_add_launch<bf16_t, bf16_t, bf16_t, false>(nullptr, x, scale, out, B, per_sample, s);
+  if (x_dtype == GE_BF16 && out_dtype == GE_F32) return scale_add_launch<bf16_t, bf16_t, float, false>(nullptr, x, scale, out, B, per_sample, s);
+  return GE_ERR_UNSUPPORTED;
+}

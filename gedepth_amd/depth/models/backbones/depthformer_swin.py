@@ -98,10 +98,14 @@ class ShiftWindowMSA(BaseModule):
         self.drop = build_dropout(dropout_layer)
         self.kernel_variant = 0
 
-    def forward(self, query, hw_shape):
+    def forward(self, query, hw_shape, identity=None):
+        """``drop(attention(query))``; with ``identity`` the residual add is folded in: ``identity + drop(...)``."""
         B, L, C = query.shape
         assert L == hw_shape[0] * hw_shape[1], 'input feature has wrong size'
-        return self.drop(self.w_msa(query, hw_shape, self.shift_size, self.kernel_variant))
+        out = self.w_msa(query, hw_shape, self.shift_size, self.kernel_variant)
+        if identity is None:
+            return self.drop(out)
+        return self.drop.residual(identity, out) if hasattr(self.drop, 'residual') else identity + self.drop(out)
 
 
 class SwinBlock(BaseModule):
@@ -122,7 +126,7 @@ class SwinBlock(BaseModule):
                        add_identity=True, init_cfg=None)
 
     def forward(self, x, hw_shape):
-        x = x + self.attn(self.norm1(x), hw_shape)
+        x = self.attn(self.norm1(x), hw_shape, identity=x)
         return self.ffn(self.norm2(x), identity=x)
 
 

@@ -418,6 +418,42 @@ def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype or x.dtype)
 
 
+# ---------------------------------------------------------------- residual + stochastic depth
+class _ResidualDropPath(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, identity, branch, scale):
+        identity, branch = _c(identity), _c(branch)
+        B = identity.shape[0]
+        n = identity.numel() // max(B, 1)
+        out = torch.empty_like(identity)
+        PROFILER.run(f'residual_drop_path[{B}x{n} {_tag(identity)}+{_tag(branch)}]',
+                     2 * identity.numel() * _es(identity) + branch.numel() * _es(branch), lambda: hip.check(
+            hip.lib().ge_residual_scale_add(hip.ptr(identity, name='identity'), hip.dtype_code(identity), hip.ptr(branch),
+                                            hip.dtype_code(branch), hip.ptr(scale, _f32), hip.ptr(out), B, n, hip.stream()),
+            'ge_residual_scale_add'))
+        ctx.save_for_backward(scale)
+        ctx.branch_dtype = branch.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, = ctx.saved_tensors
+        dy = _c(dy)
+        B = dy.shape[0]
+        n = dy.numel() // max(B, 1)
+        d_branch = torch.empty(dy.shape, device=dy.device, dtype=ctx.branch_dtype)
+        PROFILER.run(f'scale_rows[{B}x{n} {_tag(dy)}->{_tag(d_branch)}]', dy.numel() * _es(dy) + d_branch.numel() * _es(d_branch),
+                     lambda: hip.check(hip.lib().ge_scale_rows(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(scale), hip.ptr(d_branch),
+                                                               hip.dtype_code(d_branch), B, n, hip.stream()), 'ge_scale_rows'))
+        return dy, d_branch, None
+
+
+def residual_drop_path(identity, branch, scale):
+    """identity + branch * scale[b] (per-sample stochastic depth), in the identity's dtype."""
+    return _ResidualDropPath.apply(identity, branch, scale)
+
+
 # ------------------------------------------------------------------ batch norm (training) + ReLU
 class _BNAct(torch.autograd.Function):
 

@@ -292,6 +292,21 @@ class DropPath(nn.Module):
     def forward(self, x):
         return drop_path(x, self.drop_prob, self.training)
 
+    def residual(self, identity, branch):
+        """``identity + self(branch)`` — on MI355X one mixed-precision pass (kernels.residual_drop_path) instead of ATen's
+        divide / multiply / add over the token tensor.  Same random draw as ``drop_path`` (one uniform per sample)."""
+        if (not identity.is_cuda or self.drop_prob == 0. or not self.training or identity.shape != branch.shape
+                or (identity.dtype, branch.dtype) not in _RESIDUAL_DTYPES):
+            return identity + self(branch)
+        from .. import kernels
+        keep = 1 - self.drop_prob
+        u = torch.rand((branch.shape[0],) + (1,) * (branch.ndim - 1), dtype=branch.dtype, device=branch.device)
+        scale = ((keep + u).floor().float() / keep).flatten()
+        return kernels.residual_drop_path(identity, branch, scale)
+
+
+_RESIDUAL_DTYPES = {(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)}
+
 
 @DROPOUT_LAYERS.register_module()
 class Dropout(nn.Dropout):
@@ -337,6 +352,8 @@ class FFN(BaseModule):
             return self.dropout_layer(out)
         if identity is None:
             identity = x
+        if hasattr(self.dropout_layer, 'residual'):
+            return self.dropout_layer.residual(identity, out)
         return identity + self.dropout_layer(out)
 
 

@@ -150,6 +150,17 @@ int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int x_dtype, co
                      const float* rstd, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Residual connection with per-sample stochastic depth: out[b, :] = identity[b, :] + branch[b, :] * scale[b]
+ * (`identity + DropPath(branch)` of the Swin blocks, depthformer_swin.py:461-472; scale[b] = Bernoulli(keep) / keep, f32,
+ * drawn by the caller).  out has the identity's dtype; supported (identity, branch): (f32, f32), (f32, bf16), (bf16, bf16).
+ * ge_scale_rows: out[b, :] = x[b, :] * scale[b] with a dtype change — the gradient of the branch.
+ */
+int ge_residual_scale_add(const void* identity, int id_dtype, const void* branch, int br_dtype, const float* scale,
+                          void* out, int B, long per_sample, void* stream);
+int ge_scale_rows(const void* x, int x_dtype, const float* scale, void* out, int out_dtype, int B, long per_sample,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * BatchNorm2d in training mode + (leaky-)ReLU, NCHW: the norm -> act tail of mmcv ConvModule (necks/hahi.py:150-166,
  * depthformer_swin.py:1127-1139).  y = act((x - mean_c) * rstd_c * gamma_c + beta_c) with batch statistics over (N, H, W)
  * (biased variance), running_mean / running_var updated with `momentum` (unbiased variance), save_mean / save_rstd

@@ -556,6 +556,40 @@ def test_layer_norm_module_follows_autocast(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtypes', ['f32+f32', 'f32+bf16', 'bf16+bf16'])
+@pytest.mark.parametrize('shape', [(4, 37, 96), (3, 5, 7)])
+def test_residual_drop_path(dev, dtypes, shape):
+    """identity + DropPath(branch) of the Swin blocks: mixed-precision single pass and its backward vs ATen, and the
+    DropPath module draws the same per-sample mask as the unfused formula."""
+    from gedepth_amd.kernels import residual_drop_path
+    from gedepth_amd.mmrt.bricks import DropPath, drop_path
+    ti, tb = (torch.float32 if t == 'f32' else torch.bfloat16 for t in dtypes.split('+'))
+    g = gen(8)
+    ident, br = torch.randn(*shape, generator=g).to(ti), torch.randn(*shape, generator=g).to(tb)
+    scale = torch.tensor([0.0, 1 / 0.7, 1 / 0.7, 0.0][:shape[0]])
+    go = torch.randn(*shape, generator=g).to(ti)
+    ic, bc = ident.float().clone().requires_grad_(True), br.float().clone().requires_grad_(True)
+    ref = ic + bc * scale.view(-1, 1, 1)
+    ref.backward(go.float())
+    ig, bg = ident.to(dev).requires_grad_(True), br.to(dev).requires_grad_(True)
+    out = residual_drop_path(ig, bg, scale.to(dev))
+    assert out.dtype == ti
+    out.backward(go.to(dev))
+    tol = dict(rtol=2 ** -7, atol=2 ** -7) if ti == torch.bfloat16 else dict(rtol=1e-6, atol=1e-6)
+    close(out.float(), ref, what='out', **tol)
+    close(ig.grad.float(), ic.grad, what='d identity', **tol)
+    assert bg.grad.dtype == tb
+    close(bg.grad.float(), bc.grad, what='d branch', **(dict(rtol=2 ** -7, atol=2 ** -7) if tb == torch.bfloat16 else tol))
+    m = DropPath(0.3).to(dev).train()
+    torch.manual_seed(5)
+    fused = m.residual(ident.to(dev), br.to(dev))
+    torch.manual_seed(5)
+    unfused = ident.to(dev) + drop_path(br.to(dev), 0.3, True)
+    # the unfused formula rounds branch / keep to the branch dtype first; the fused pass keeps it in fp32
+    close(fused.float(), unfused.float(), what='module', **(dict(rtol=2 ** -7, atol=2 ** -7) if tb == torch.bfloat16 else tol))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 5, 7, 9), (3, 16, 12, 16), (2, 64, 24, 40)])
 @pytest.mark.parametrize('slope', [0.0, 1.0])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
