@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ....kernels import window_attention
-from ....mmrt.bricks import (FFN, BaseModule, ModuleList, build_conv_layer, build_dropout, build_norm_layer,
+from ....mmrt.bricks import (FFN, BaseModule, Linear, ModuleList, build_conv_layer, build_dropout, build_norm_layer,
                              constant_init, trunc_normal_init)
 from ...ops import resize
 from ..builder import BACKBONES
@@ -32,7 +32,7 @@ class PatchMerging(BaseModule):
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
         sample_dim = stride ** 2 * in_channels
         self.norm = build_norm_layer(norm_cfg, sample_dim)[1] if norm_cfg is not None else None
-        self.reduction = nn.Linear(sample_dim, out_channels, bias=bias)
+        self.reduction = Linear(sample_dim, out_channels, bias=bias)
 
     def forward(self, x, hw_shape):
         B, L, C = x.shape
@@ -68,8 +68,8 @@ class WindowMSA(BaseModule):
         j = torch.arange(Wh * Ww) % Ww
         index = (i[:, None] - i[None, :] + Wh - 1) * (2 * Ww - 1) + (j[:, None] - j[None, :] + Ww - 1)
         self.register_buffer('relative_position_index', index.contiguous())
-        self.qkv = nn.Linear(embed_dims, embed_dims * 3, bias=qkv_bias)
-        self.proj = nn.Linear(embed_dims, embed_dims)
+        self.qkv = Linear(embed_dims, embed_dims * 3, bias=qkv_bias)
+        self.proj = Linear(embed_dims, embed_dims)
         self.proj_drop = nn.Dropout(proj_drop_rate)
 
     def init_weights(self):

@@ -38,8 +38,8 @@ class MultiScaleDeformableAttention(BaseModule):
         self.embed_dims, self.num_levels, self.num_heads, self.num_points = embed_dims, num_levels, num_heads, num_points
         self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
         self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.value_proj = bricks.Linear(embed_dims, embed_dims)
+        self.output_proj = bricks.Linear(embed_dims, embed_dims)
         self.init_weights()
 
     def init_weights(self):
@@ -69,7 +69,7 @@ class MultiScaleDeformableAttention(BaseModule):
         nH, L, P = self.num_heads, self.num_levels, self.num_points
         w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
         b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-        raw = F.linear(query, w, b)                           # (B, Nq, nH*L*P*2 + nH*L*P)
+        raw = bricks.linear_tokens(query, w, b)               # (B, Nq, nH*L*P*2 + nH*L*P)
         # sampling locations / weights are fp32 (pixel coordinates up to ~1000 need > 8 mantissa bits)
         loc, weights = msda_prepare(raw, reference_points.expand(bs, num_query, L, 2), spatial_shapes, nH, L, P)
         out = ms_deform_attn(value, spatial_shapes, loc, weights)

@@ -13,6 +13,7 @@ import warnings
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .registry import Registry, build_from_cfg
 
@@ -102,6 +103,73 @@ class ModuleList(BaseModule, nn.ModuleList):
 
 
 # ----------------------------------------------------------------------------------- layers
+def _split_k(tokens):
+    """Number of K-chunks for the weight gradient of a Linear over ``tokens`` rows (0: leave it to the library)."""
+    if tokens < 32768:
+        return 0
+    s = 64
+    while s > 1 and tokens % s:
+        s //= 2
+    while s > 1 and tokens // s < 1024:
+        s //= 2
+    return s if s >= 4 else 0
+
+
+class _LinearTokens(torch.autograd.Function):
+    """``F.linear`` whose weight gradient is computed split-K.  dW = dY^T X has an output of at most 768 x 768 and a
+    reduction over 5e4 - 8e5 tokens: the libraries run it as one GEMM on a handful of output tiles (hipBLASLt / rocBLAS,
+    best tuned solution: 18 - 365 TFLOP/s on MI355X); as a batched GEMM over S token chunks plus an fp32 sum of the S
+    partial products it fills the chip (2 - 4x faster, scratch/wgrad_splitk.py) and the result is accumulated in fp32
+    instead of being rounded to bf16 first.  Forward and input gradient are the library GEMMs unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, splits):
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
+        with torch.autocast('cuda', enabled=False):
+            xc, wc = x.to(dt), weight.to(dt)
+            y = F.linear(xc, wc, None if bias is None else bias.to(dt))
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (splits, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        splits, x_dtype, w_dtype, b_dtype = ctx.meta
+        K = xc.numel() // xc.shape[-1]
+        with torch.autocast('cuda', enabled=False):
+            dy2 = dy.to(wc.dtype).reshape(K, -1)
+            x2 = xc.reshape(K, -1)
+            dx = dw = db = None
+            if ctx.needs_input_grad[0]:
+                dx = (dy2 @ wc).reshape(xc.shape).to(x_dtype)
+            if ctx.needs_input_grad[1]:
+                if splits:
+                    M, N = dy2.shape[1], x2.shape[1]
+                    part = torch.bmm(dy2.view(splits, K // splits, M).transpose(1, 2), x2.view(splits, K // splits, N))
+                    dw = part.sum(0, dtype=torch.float32).to(w_dtype)
+                else:
+                    dw = (dy2.t() @ x2).to(w_dtype)
+            if b_dtype is not None and ctx.needs_input_grad[2]:
+                db = dy2.sum(0, dtype=torch.float32).to(b_dtype)
+        return dx, dw, db, None
+
+
+def linear_tokens(x, weight, bias=None):
+    """``F.linear`` for token matrices: split-K weight gradient when the token count is large (see _LinearTokens)."""
+    splits = _split_k(x.numel() // x.shape[-1]) if (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad) else 0
+    if not splits or x.dtype not in (torch.float32, torch.bfloat16):
+        return F.linear(x, weight, bias)
+    return _LinearTokens.apply(x, weight, bias, splits)
+
+
+class Linear(nn.Linear):
+    """``nn.Linear`` (same parameters / state-dict keys) over token matrices, see ``linear_tokens``."""
+
+    def forward(self, x):
+        return linear_tokens(x, self.weight, self.bias)
+
+
 class LayerNorm(nn.LayerNorm):
     """``nn.LayerNorm`` (same parameters / state-dict keys) running as one mixed-precision HIP kernel on MI355X: bf16 or
     fp32 tokens in, fp32 statistics, and — under autocast — bf16 out for the Linear that follows, instead of ATen's
@@ -337,10 +405,10 @@ class FFN(BaseModule):
         self.activate = build_activation_layer(act_cfg)
         layers, in_channels = [], embed_dims
         for _ in range(num_fcs - 1):
-            layers.append(Sequential(nn.Linear(in_channels, feedforward_channels), self.activate,
+            layers.append(Sequential(Linear(in_channels, feedforward_channels), self.activate,
                                      nn.Dropout(ffn_drop)))
             in_channels = feedforward_channels
-        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(Linear(feedforward_channels, embed_dims))
         layers.append(nn.Dropout(ffn_drop))
         self.layers = Sequential(*layers)
         self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()

@@ -556,6 +556,34 @@ def test_layer_norm_module_follows_autocast(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('autocast', [False, True])
+def test_linear_tokens_split_k_weight_gradient(dev, autocast):
+    """Linear over a large token matrix: output and all gradients equal F.linear's (the weight gradient is summed over
+    token chunks in fp32 instead of one library GEMM)."""
+    from gedepth_amd.mmrt.bricks import Linear, _split_k
+    assert _split_k(788480) == 64 and _split_k(261800) == 8 and _split_k(49280) == 32 and _split_k(4000) == 0
+    torch.manual_seed(0)
+    lin = Linear(96, 160).to(dev)
+    x = torch.randn(2, 24640, 96, device=dev, requires_grad=True)          # 49280 tokens -> 32 chunks
+    go = torch.randn(2, 24640, 160, device=dev)
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        y = lin(x)
+        ref = F.linear(x, lin.weight, lin.bias)
+    assert y.dtype == ref.dtype and torch.equal(y, ref)
+    y.backward(go.to(y.dtype))
+    gx, gw, gb = x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()
+    x.grad = None; lin.zero_grad()
+    ref.backward(go.to(ref.dtype))
+    tol = 2e-2 if autocast else 1e-4                                        # bf16: the library rounds dW to bf16, split-K does not
+    assert (gx - x.grad).norm() <= tol * x.grad.norm()
+    assert (gw - lin.weight.grad).norm() <= tol * lin.weight.grad.norm()
+    assert (gb - lin.bias.grad).norm() <= tol * lin.bias.grad.norm()
+    if autocast:                                                            # and it is the more accurate of the two
+        exact = go.reshape(-1, 160).bfloat16().double().t() @ x.detach().reshape(-1, 96).bfloat16().double()
+        assert (gw.double() - exact).norm() <= (lin.weight.grad.double() - exact).norm()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('dtypes', ['f32+f32', 'f32+bf16', 'bf16+bf16'])
 @pytest.mark.parametrize('shape', [(4, 37, 96), (3, 5, 7)])
 def test_residual_drop_path(dev, dtypes, shape):
