@@ -10,7 +10,7 @@ are not in the file use the library default.  ``tools/tune_gemms.py`` regenerate
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-GEMM_TABLE = os.path.join(os.path.dirname(_HERE), 'tuning', 'tunableop_gfx950.csv')
+GEMM_TABLE = os.environ.get('GE_GEMM_TABLE') or os.path.join(os.path.dirname(_HERE), 'tuning', 'tunableop_gfx950.csv')
 MIOPEN_DB = os.path.join(os.path.dirname(_HERE), 'tuning', 'miopen')
 
 
