@@ -107,12 +107,10 @@ def _split_k(tokens):
     """Number of K-chunks for the weight gradient of a Linear over ``tokens`` rows (0: leave it to the library)."""
     if tokens < 32768:
         return 0
-    s = 64
-    while s > 1 and tokens % s:
-        s //= 2
-    while s > 1 and tokens // s < 1024:
-        s //= 2
-    return s if s >= 4 else 0
+    for s in range(64, 3, -1):                    # the largest divisor <= 64 that leaves chunks of >= 1024 tokens
+        if tokens % s == 0 and tokens // s >= 1024:
+            return s
+    return 0
 
 
 class _LinearTokens(torch.autograd.Function):
