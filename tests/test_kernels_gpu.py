@@ -264,7 +264,8 @@ def test_msda_module_golden(dev, golden):
 # ============================================================================== bilinear
 @pytest.mark.parametrize('align', [False, True])
 @pytest.mark.parametrize('sizes', [((11, 35), (22, 70)), ((22, 70), (11, 35)), ((7, 9), (16, 31)), ((16, 31), (7, 9)),
-                                   ((5, 6), (5, 6)), ((1, 2), (8, 12)), ((176, 560), (352, 1120))])
+                                   ((5, 6), (5, 6)), ((1, 2), (8, 12)), ((176, 560), (352, 1120)), ((11, 35), (176, 560)),
+                                   ((3, 5), (13, 17))])
 def test_bilinear_fwd_bwd(dev, align, sizes):
     from gedepth_amd.kernels import bilinear_resize
     (hi, wi), (ho, wo) = sizes
