@@ -1,13 +1,12 @@
 // Multi-scale deformable attention sampling core for gfx950 (replaces mmcv's ms_deform_attn CUDA op,
 // reference call sites depth/models/necks/hahi.py:279-289,316-325).
 //
-// Work decomposition (wave64-first): a group of 16 lanes owns one (batch, query, head); each lane owns
-// 4 of the head's 64 channels, so every bilinear tap is one 256-byte (fp32) / 128-byte (bf16)
-// fully-coalesced read of `value`.  A 256-thread workgroup therefore covers 16 (query, head) pairs =
-// two whole queries, whose sampling locations / attention weights are contiguous in memory.
-// The op is a gather (no contraction) -> no MFMA; it is bound by L2/MALL gather bandwidth.
-// Backward accumulates d_value with fp32 hardware atomics (global_atomic_add_f32) and reduces
-// d_loc / d_attw over the 64 channels with 16-lane butterfly shuffles.
+// Work decomposition (wave64-first): a group of 8 (bf16) / 16 (fp32) lanes owns one (batch, query, head); each lane owns
+// 16 bytes of the head's 64 channels, so every bilinear corner is one fully coalesced 128 / 256-byte read of `value` and a
+// wave fetches 8 / 4 rows per instruction.  A wave covers the heads of one query, whose sampling locations / attention
+// weights are contiguous in memory.  The op is a gather (no contraction) -> no MFMA; forward and the d_loc / d_attw pass are
+// bound by the vector-L1 gather path.  d_value is a scatter: a counting sort of (point, tile) records +
+// register-tile accumulation (below), with the direct fp32-atomic scatter kept as the no-workspace fallback.
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
@@ -61,18 +60,6 @@ template <> struct VecL<bf16_t> {
     t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
     *(uint4*)p = t;
   }
-};
-
-template <typename T> struct Vec4Raw;      // 4 channels, raw storage bits (no conversion): gather -> LDS staging
-template <> struct Vec4Raw<float> {
-  typedef float4 type;
-  static __device__ __forceinline__ float4 ld(const float* p) { return *(const float4*)p; }
-  static __device__ __forceinline__ void st(float* p, const float4& v) { *(float4*)p = v; }
-};
-template <> struct Vec4Raw<bf16_t> {
-  typedef uint2 type;
-  static __device__ __forceinline__ uint2 ld(const bf16_t* p) { return *(const uint2*)p; }
-  static __device__ __forceinline__ void st(bf16_t* p, const uint2& v) { *(uint2*)p = v; }
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
