@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
 // four statically addressed accumulators (the 2 x 2 corners) with two packed FMAs per record.  Classes are visited in
 // raster order, so the right-hand pair of one class is the left-hand pair of the next: per class step two accumulators
 // are written to the register tile through `s_set_gpr_idx` and two are carried over.
-#define MSDA_SUB 768
+#define MSDA_SUB 512           // measured 256 / 512 / 768: 5.0 / 4.3 / 5.2 ms (LDS per wave sets the occupancy, class runs get shorter)
 #define MSDA_NCLS 45           // (ly+1) in [0,4] x (lx+1) in [0,8]
 template <typename T>
 __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins, MsdaWs ws, const T* __restrict__ gout,
@@ -921,9 +921,9 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   GE_LAUNCH_CHECK();
   msda_mark(ev, 4, s);
   if (dtype == GE_F32)
-    msda_drain_k<float><<<256 * 2, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
+    msda_drain_k<float><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
   else
-    msda_drain_k<bf16_t><<<256 * 2, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
+    msda_drain_k<bf16_t><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 5, s);
   if (ev) {
