@@ -309,17 +309,12 @@ class ConvModule(nn.Module):
         slope = self._fused_slope() if x.is_cuda else None
         if slope is not None:
             return conv_bias_act(self.conv, x, slope)
-        if x.is_cuda and self.with_norm:
-            slope = self._fused_bn_slope()
-            if slope is not None:
-                from .. import kernels
-                y = self.conv(x)
-                if y.dtype in (torch.float32, torch.bfloat16):
-                    return kernels.bn_act(y, self.norm, slope)
-                x = y
-                x = self.norm(x)
-                return self.activate(x) if self.with_activation else x
         x = self.conv(x)
+        if x.is_cuda and self.with_norm and x.dtype in (torch.float32, torch.bfloat16):
+            slope = self._fused_bn_slope()
+            if slope is not None:                       # training-mode BatchNorm2d (+ ReLU): the fused HIP kernels
+                from .. import kernels
+                return kernels.bn_act(x, self.norm, slope)
         if self.with_norm:
             x = self.norm(x)
         if self.with_activation:
