@@ -45,7 +45,14 @@ def use_miopen_find_db(path=MIOPEN_DB):
     files = [f for f in (os.listdir(path) if os.path.isdir(path) else []) if f.endswith('db.txt')]
     if not files:
         return False
-    dst = os.path.join(tempfile.gettempdir(), f'gedepth_amd_miopen_db_{os.getuid()}_{os.environ.get("LOCAL_RANK", "0")}')
+    import hashlib
+    digest = hashlib.sha1()
+    for f in sorted(files):
+        with open(os.path.join(path, f), 'rb') as fh:
+            digest.update(fh.read())
+    # one scratch copy per committed content, user and rank: an updated db never hides behind a stale copy
+    dst = os.path.join(tempfile.gettempdir(), f'gedepth_amd_miopen_db_{digest.hexdigest()[:10]}_{os.getuid()}_'
+                                              f'{os.environ.get("LOCAL_RANK", "0")}')
     os.makedirs(dst, exist_ok=True)
     for f in files:
         if not os.path.isfile(os.path.join(dst, f)):
