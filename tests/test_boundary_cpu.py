@@ -147,3 +147,39 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any launch, so these are safe without a GPU
     assert hip.lib().ge_bilinear_fwd(None, None, 1, 1, 4, 4, 8, 8, 0, 0, None) == 10001
     assert hip.lib().ge_window_attn_bwd_workspace(2, 11, 35, 3) > 0
+
+
+def test_official_swin_checkpoint_loads_like_the_reference(golden):
+    """§8 f2: ``DepthFormerSwin.load_pretrained`` on an official-layout Swin checkpoint (5x5-window bias tables, 3-channel
+    patch embedding) gives the tensors the reference's ``init_weights`` produced from the same file
+    (tests/golden/make_golden_ckpt.py): key renames, unfold-order fix, bicubic table resize, zero 4th input channel."""
+    import importlib.util
+    import os.path as osp
+    import tempfile
+    spec = importlib.util.spec_from_file_location('make_golden_ckpt', osp.join(osp.dirname(__file__), 'golden', 'make_golden_ckpt.py'))
+    gen_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen_mod)
+    g = golden('swin_official_ckpt')
+    from gedepth_amd.depth.models.builder import BACKBONES
+    from gedepth_amd.mmrt.registry import build_from_cfg
+    cfg = dict(type='DepthFormerSwin', pretrain_img_size=224, patch_size=4, window_size=7, mlp_ratio=4, strides=(4, 2, 2, 2),
+               out_indices=(0, 1, 2, 3), qkv_bias=True, qk_scale=None, patch_norm=True, drop_rate=0., attn_drop_rate=0.,
+               drop_path_rate=0.0, use_abs_pos_embed=False, act_cfg=dict(type='GELU'), norm_cfg=dict(type='LN', requires_grad=True),
+               pretrain_style='official', conv_norm_cfg=dict(type='BN', requires_grad=True), depth=50, num_stages=0, USEPE=True,
+               **gen_mod.ARCH)
+    m = build_from_cfg(cfg, BACKBONES)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = osp.join(tmp, 'swin_official.pth')
+        torch.save({'model': gen_mod.fake_official_swin()}, path)
+        m.load_pretrained(path)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == [str(k) for k in g['all_keys']]
+    checked = 0
+    for k in g.files:
+        if k.startswith('key::'):
+            ref = torch.from_numpy(g[k])
+            assert torch.allclose(sd[k[5:]].float(), ref.float(), rtol=1e-6, atol=1e-6), k
+            checked += 1
+    assert checked >= 20
+    w = sd['patch_embed.projection.weight']
+    assert w.shape[1] == 4 and float(w[:, 3].abs().max()) == 0.0
