@@ -184,3 +184,48 @@ def test_runner_hooks_checkpoint_resume(tmp_path):
     assert r2.iter == 12
     for k, v in model.state_dict().items():
         assert torch.equal(v, model2.state_dict()[k])
+
+
+# ---------------------------------------------------------------- distributed evaluation (depth/apis/test.py)
+class _IndexDataset(torch.utils.data.Dataset):
+    """5 samples (odd on purpose: the DistributedSampler pads rank 1 with a repeated index)."""
+
+    def __len__(self):
+        return 5
+
+    def __getitem__(self, i):
+        return dict(img=[torch.full((1, 2, 2), float(i))], img_metas=[dict(index=i)])
+
+    def pre_eval(self, preds, indices):
+        return [(float(p.mean()), i) for p, i in zip(preds, indices)], preds
+
+
+class _Echo(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.p = nn.Parameter(torch.zeros(1))
+
+    def forward(self, img, img_metas, return_loss=True, **kw):
+        assert return_loss is False
+        return [t.numpy() for t in img[0]]
+
+
+def _eval_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gedepth_amd.depth.apis.test import multi_gpu_test
+    from gedepth_amd.depth.datasets import build_dataloader
+    loader = build_dataloader(_IndexDataset(), 1, 0, dist=True, shuffle=False, pin_memory=False)
+    res = multi_gpu_test(_Echo(), loader, pre_eval=True, device='cpu')
+    torch.save(res, os.path.join(tmp, f'eval{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_multi_gpu_test_returns_dataset_order_on_rank0(tmp_path):
+    port = free_port()
+    mp.spawn(_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'eval0.pt', weights_only=False)
+    r1 = torch.load(tmp_path / 'eval1.pt', weights_only=False)
+    assert r1 is None
+    assert [v for v, _ in r0] == [0.0, 1.0, 2.0, 3.0, 4.0] and [i for _, i in r0] == [0, 1, 2, 3, 4]
