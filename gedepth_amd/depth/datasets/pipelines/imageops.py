@@ -129,3 +129,31 @@ def imrotate(img, angle, center=None, scale=1.0, border_value=0, interpolation='
         out = np.clip(np.rint(out), 0, 255)
     out = out.astype(img.dtype)
     return out[..., 0] if squeeze else out
+
+
+def _area_weights(n_in, n_out):
+    """(n_out, n_in) row-stochastic matrix of cv2.INTER_AREA when shrinking: output cell j averages the source interval
+    [j * s, (j + 1) * s), s = n_in / n_out, each source pixel weighted by its overlap."""
+    s = n_in / n_out
+    w = np.zeros((n_out, n_in), dtype=np.float64)
+    for j in range(n_out):
+        lo, hi = j * s, (j + 1) * s
+        i0, i1 = int(np.floor(lo)), min(int(np.ceil(hi)), n_in)
+        for i in range(i0, i1):
+            w[j, i] = min(hi, i + 1) - max(lo, i)
+    return w / w.sum(1, keepdims=True)
+
+
+def imresize_area(img, size):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_AREA) for down-scaling (pixel-area averaging); up-scaling falls
+    back to bilinear like OpenCV's INTER_AREA does for factors < 1 per axis."""
+    h, w = img.shape[:2]
+    ow, oh = int(size[0]), int(size[1])
+    if ow > w or oh > h:
+        return imresize(img, size, interpolation='bilinear')
+    src = img.astype(np.float64)
+    out = np.tensordot(_area_weights(h, oh), src, axes=(1, 0))                    # (oh, w, ...)
+    out = np.moveaxis(np.tensordot(_area_weights(w, ow), out, axes=(1, 1)), 0, 1)  # (oh, ow, ...)
+    if img.dtype == np.uint8:
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    return out.astype(img.dtype)

@@ -107,3 +107,87 @@ class LoadImageFromFile:
 
     def __repr__(self):
         return f"{self.__class__.__name__}(to_float32={self.to_float32}, color_type='{self.color_type}', USEPE={self.USEPE})"
+
+
+_DDAD_CAMERA_HEIGHT = {'CAMERA_01': 1.56, 'CAMERA_05': 1.57, 'CAMERA_06': 1.53, 'CAMERA_09': 1.53}
+
+
+@PIPELINES.register_module()
+class LoadDDADCamIntrinsic:
+    """loading.py:958-978: the camera name is the parent directory of the image."""
+
+    def __call__(self, results):
+        results['cam_intrinsic'] = results['cam_intrinsic_dict'][results['filename'].split('/')[-2]]
+        return results
+
+    def __repr__(self):
+        return self.__class__.__name__
+
+
+@PIPELINES.register_module()
+class DDADDepthLoadAnnotations:
+    """loading.py:743-801: depth from ``<...>.npz['depth']``; with ``USE_DYNAMIC_PE`` the slope classes from the sibling
+    ``*_slope_public_debug.npz`` (``k_img + 5``, 255 kept as ignore)."""
+
+    def __init__(self, USE_DYNAMIC_PE=False, file_client_args=None, imdecode_backend='pillow'):
+        self.USE_DYNAMIC_PE, self.imdecode_backend = USE_DYNAMIC_PE, imdecode_backend
+
+    def __call__(self, results):
+        filename = results['ann_info']['depth_map']
+        depth_gt = np.load(filename)['depth']
+        results['depth_gt'] = depth_gt
+        results['depth_ori_shape'] = depth_gt.shape
+        results['depth_fields'].append('depth_gt')
+        if self.USE_DYNAMIC_PE:
+            k = np.load(filename.replace('depth_val', 'depth').replace('.npz', '_slope_public_debug.npz'))['k_img'].astype(np.float32)
+            ignore = k == 255
+            k = k + 5
+            k[ignore] = 255
+            results['pe_k_gt'] = k.astype(np.float32)
+            results['depth_fields'].append('pe_k_gt')
+        return results
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(imdecode_backend='{self.imdecode_backend}')"
+
+
+@PIPELINES.register_module()
+class LoadDDADImageFromFile:
+    """loading.py:804-955: BGR image + per-camera ground depth ``<pe_root>/<camera>/ddad_pe.npz['pe']`` (channel 3:
+    values outside [0, 250] zeroed; channel 4, with ``USE_DYNAMIC_PE``: raw) and the camera height / ``test`` flag the
+    adaptive ground embedding needs (encoder_decoder.py:88-94).  ``pe_root`` replaces ``data/DDAD/pe_public_debug``."""
+
+    def __init__(self, to_float32=False, color_type='color', file_client_args=None, imdecode_backend='cv2', USEPE=False,
+                 USE_DYNAMIC_PE=False, pe_root=None):
+        self.to_float32, self.color_type, self.imdecode_backend = to_float32, color_type, imdecode_backend
+        self.USEPE, self.USE_DYNAMIC_PE = USEPE, USE_DYNAMIC_PE
+        self.pe_root = pe_root if pe_root is not None else osp.join('data', 'DDAD', 'pe_public_debug')
+
+    def __call__(self, results):
+        name = results['img_info']['filename']
+        filename = osp.join(results['img_prefix'], name) if results.get('img_prefix') is not None else name
+        img = np.ascontiguousarray(np.asarray(Image.open(filename).convert('RGB'))[..., ::-1])
+        if self.to_float32:
+            img = img.astype(np.float32)
+        results['filename'] = filename
+        results['ori_filename'] = name
+        if self.USEPE:
+            camera = results['ann_info']['depth_map'].split('/')[-2]
+            pe_raw = np.load(osp.join(self.pe_root, camera, 'ddad_pe.npz'))['pe']
+            pe = pe_raw.copy()
+            pe[pe > 250] = 0
+            pe[pe < 0] = 0
+            img = np.concatenate((img, pe[..., None]), axis=-1)
+            if self.USE_DYNAMIC_PE:
+                img = np.concatenate((img, pe_raw[..., None]), axis=-1)
+                results['height'] = next(h for cam, h in _DDAD_CAMERA_HEIGHT.items() if cam in filename)
+                results['test'] = 0
+        results['img'] = img
+        results['img_shape'] = results['ori_shape'] = results['pad_shape'] = img.shape
+        results['scale_factor'] = 1.0
+        c = 1 if img.ndim < 3 else img.shape[2]
+        results['img_norm_cfg'] = dict(mean=np.zeros(c, dtype=np.float32), std=np.ones(c, dtype=np.float32), to_rgb=False)
+        return results
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(to_float32={self.to_float32}, color_type='{self.color_type}', USEPE={self.USEPE})"

@@ -7,7 +7,7 @@ import random
 import numpy as np
 
 from ..builder import PIPELINES
-from .imageops import imflip, imnormalize, imrescale, imresize, imrotate
+from .imageops import imflip, imnormalize, imrescale, imresize, imresize_area, imrotate
 
 
 @PIPELINES.register_module()
@@ -259,3 +259,43 @@ class Resize:
     def __repr__(self):
         return (f'{self.__class__.__name__}(img_scale={self.img_scale}, multiscale_mode={self.multiscale_mode}, '
                 f'ratio_range={self.ratio_range}, keep_ratio={self.keep_ratio})')
+
+
+@PIPELINES.register_module()
+class DDADResize:
+    """transforms.py:736-783: colour by area averaging, ground-depth channels by nearest neighbour; the sparse LiDAR depth
+    (and slope classes) are re-projected point by point — each valid pixel lands at ``int(coord * scale)`` — so no depth is
+    interpolated."""
+
+    def __init__(self, shape, depth=True, USE_DYNAMIC_PE=False):
+        self.shape, self.depth, self.USE_DYNAMIC_PE = tuple(shape), depth, USE_DYNAMIC_PE
+
+    def _splat(self, x):
+        h, w = x.shape
+        ys, xs = np.nonzero(x > 0)
+        val = x[ys, xs]
+        ys = (ys * (self.shape[0] / h)).astype(np.int32)
+        xs = (xs * (self.shape[1] / w)).astype(np.int32)
+        keep = (ys < self.shape[0]) & (xs < self.shape[1])
+        out = np.zeros(self.shape)
+        out[ys[keep], xs[keep]] = val[keep]                 # row-major order: the last source pixel wins, as upstream
+        return out
+
+    def __call__(self, results):
+        img_pe = results['img']
+        size = self.shape[::-1]
+        if img_pe.shape[-1] == 5:
+            img = imresize_area(img_pe[:, :, 0:3].copy().astype(np.uint8), size)
+            pe = imresize(img_pe[:, :, 3].copy().astype(np.float32), size, interpolation='nearest')
+            pe_raw = imresize(img_pe[:, :, 4].copy().astype(np.float32), size, interpolation='nearest')
+            results['img'] = np.concatenate([img, pe[:, :, None], pe_raw[:, :, None]], axis=-1).astype(np.float32)
+        else:
+            results['img'] = imresize_area(img_pe, size)
+        if self.depth:
+            results['depth_gt'] = self._splat(results['depth_gt'])
+            if self.USE_DYNAMIC_PE:
+                results['pe_k_gt'] = self._splat(results['pe_k_gt'])
+        return results
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}(shape={self.shape}, depth={self.depth})'
