@@ -44,7 +44,7 @@ def test_config_inheritance_and_delete():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree only exists in the build container')
-@pytest.mark.parametrize('name', ['depthformer_v.py', 'depthformer_a.py'])
+@pytest.mark.parametrize('name', ['depthformer_v.py', 'depthformer_a.py', 'depthformer_a_ddad.py', 'depthformer_v_ddad.py'])
 def test_reference_configs_load_unchanged_and_resolve_identically(name):
     """The reference's own config files load byte-unchanged through our loader, and our re-structured
     configs resolve to the same model / optimizer / schedule."""
