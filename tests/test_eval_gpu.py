@@ -73,3 +73,56 @@ def test_train_step_on_pipeline_batch(setup):
     out['loss'].backward()
     opt.step()
     assert np.isfinite(float(out['log_vars']['loss']))
+
+
+def test_ddad_adaptive_train_and_eval_with_camera_heights(tmp_path):
+    """§8 f4: GEDepth-Adaptive on DDAD-style samples — per-sample camera ``height`` reaches the ground-embedding kernel in
+    training (tensor) and in testing (list over augmentations + ``test`` flag, encoder_decoder.py:88-94)."""
+    from test_dataset_cpu import _make_toy_ddad
+    root = str(tmp_path)
+    split = _make_toy_ddad(root)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_a.py'))
+    cfg.model.pretrained = None
+    cfg.model.depth_scale = 250
+    torch.manual_seed(0)
+    model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    model.init_weights()
+    model = model.cuda()
+    ddad = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_a_ddad.py'))
+    shape = (96, 160)
+
+    def patch(pipeline):
+        out = []
+        for t in pipeline:
+            t = dict(t)
+            if t['type'] == 'LoadDDADImageFromFile':
+                t['pe_root'] = os.path.join(root, 'pe')
+            if t['type'] == 'DDADResize':
+                t['shape'] = shape
+            if t['type'] == 'Padding':
+                t['ori_h'], t['ori_w'] = shape
+            if t['type'] == 'RandomCrop':
+                t['crop_size'] = shape
+            if t['type'] == 'MultiScaleFlipAug':
+                t['img_scale'] = shape
+            out.append(t)
+        return out
+    tr = dict(ddad.data.train); tr.update(pipeline=patch(ddad.data.train.pipeline), split=split)
+    te = dict(ddad.data.test); te.update(pipeline=patch(ddad.data.test.pipeline), split=split)
+    random.seed(0); np.random.seed(0)
+    train_set = build_dataset(tr)
+    batch = next(iter(build_dataloader(train_set, 2, 0, dist=False, shuffle=False, drop_last=True)))
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert batch['height'].shape == (2,)
+    model.train()
+    opt = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    opt.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model.train_step(batch, opt)
+    out['loss'].backward()
+    opt.step()
+    assert np.isfinite(float(out['log_vars']['loss'])) and 'decode.loss_dynamic_pe' in out['log_vars']
+    test_set = build_dataset(te, dict(test_mode=True))
+    res = single_gpu_test(model, build_dataloader(test_set, 1, 0, dist=False, shuffle=False), pre_eval=True)
+    summary = test_set.evaluate(res)
+    assert len(res) == len(test_set) == 4 and all(np.isfinite(v) for v in summary.values())
