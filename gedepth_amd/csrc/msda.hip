@@ -435,22 +435,36 @@ struct MsdaWs {            // device workspace carved by the host wrapper
 #define MSDA_SEG 65536
 template <bool FILL>
 __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
-                                                   const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P, int nseg, int B) {
-  extern __shared__ int hist[];                          // [nH * ntiles]
+                                                   const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P, int nseg, int B,
+                                                   int hsplit) {
+  // hsplit == 1: the workgroup's LDS histogram covers all heads ([nH * ntiles] counters).  hsplit == nH (large maps, e.g.
+  // 1216 x 1936: 6e3 tiles x 8 heads would not fit): one workgroup per (segment, head) with [ntiles] counters, visiting only
+  // that head's (query, head) groups of the segment — still L*P consecutive points, i.e. coalesced.
+  extern __shared__ int hist[];
   const int ntiles = bins.first_tile[L];
   const int nloc = nH * ntiles;
   const int LP = L * P;
   const long vb = msda_xcd_block(blockIdx.x, gridDim.x);        // neighbouring segments (same value tiles) share an XCD
-  if (vb >= (long)nseg * B) return;
-  const int b = (int)(vb / nseg), seg = (int)(vb - (long)b * nseg);
+  if (vb >= (long)nseg * B * hsplit) return;
+  const int hsel = (int)(vb % hsplit);
+  const long sb = vb / hsplit;
+  const int b = (int)(sb / nseg), seg = (int)(sb - (long)b * nseg);
   const long npts_b = (long)Nq * nH * LP;
-  int* gh = ws.seg_hist + ((long)b * nseg + seg) * nloc;
-  for (int i = threadIdx.x; i < nloc; i += 256) hist[i] = FILL ? gh[i] : 0;
+  const int nwg = hsplit == 1 ? nloc : ntiles;            // counters of this workgroup
+  const int wg0 = hsplit == 1 ? 0 : hsel * ntiles;        // ... starting at this bin of the (batch, segment) histogram
+  int* gh = ws.seg_hist + ((long)b * nseg + seg) * nloc + wg0;
+  for (int i = threadIdx.x; i < nwg; i += 256) hist[i] = FILL ? gh[i] : 0;
   __syncthreads();
-  const long p_lo = (long)seg * MSDA_SEG, p_hi = min(npts_b, p_lo + MSDA_SEG);
-  for (long ib = p_lo + threadIdx.x; ib < p_hi; ib += 256) {
-    const int grp_b = (int)(ib / LP);                    // q*nH + head
-    const int lp = (int)(ib - (long)grp_b * LP);
+  const long p_lo = (long)seg * MSDA_SEG, p_hi = min(npts_b, p_lo + MSDA_SEG);    // MSDA_SEG is a multiple of L * P
+  const long g_lo = p_lo / LP, g_hi = p_hi / LP;          // (query, head) groups of the segment
+  const long g_first = hsplit == 1 ? g_lo : g_lo + ((hsel - g_lo % nH) + nH) % nH;
+  const long g_step = hsplit == 1 ? 1 : nH;
+  const long n_local = g_first < g_hi ? ((g_hi - g_first + g_step - 1) / g_step) * LP : 0;
+  for (long j = threadIdx.x; j < n_local; j += 256) {
+    const long grp_l = g_first + (j / LP) * g_step;
+    const int grp_b = (int)grp_l;                        // q*nH + head
+    const int lp = (int)(j % LP);
+    const long ib = grp_l * LP + lp;
     const int l = lp / P;
     const int q = grp_b / nH, head = grp_b - q * nH;
     const int Hl = lv.H[l], Wl = lv.W[l];
@@ -463,7 +477,7 @@ __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins,
     const float ax = x - xf, ay = y - yf;
     const float wgt = FILL ? attw[pt] : 0.f;
     const int ntx = bins.ntx[l];
-    const int lb0 = head * ntiles + bins.first_tile[l];
+    const int lb0 = head * ntiles + bins.first_tile[l] - wg0;
     // tile columns / rows that hold an in-image corner: the left column x0 (if >= 0) and the right column x0+1 (if < W)
     const bool xa = x0 >= 0, xb = x0 + 1 < Wl, ya = y0 >= 0, yb = y0 + 1 < Hl;
     const int txa = x0 >> 3, txb = (x0 + 1) >> 3, tya = y0 >> 2, tyb = (y0 + 1) >> 2;
@@ -481,10 +495,10 @@ __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins,
   }
   if (!FILL) {
     __syncthreads();
-    for (int i = threadIdx.x; i < nloc; i += 256) {
+    for (int i = threadIdx.x; i < nwg; i += 256) {
       const int c = hist[i];
       gh[i] = c;
-      if (c) atomicAdd(&ws.cnt[b * nloc + i], c);
+      if (c) atomicAdd(&ws.cnt[b * nloc + wg0 + i], c);
     }
   }
 }
@@ -738,7 +752,7 @@ static size_t msda_ws_layout(int nbins, long seg_hist_ints, long max_entries, ch
   }
   return off;
 }
-struct MsdaPlan { int ntiles, nloc, nseg, nbins; long max_entries; bool ok; };
+struct MsdaPlan { int ntiles, nloc, nseg, nbins, hsplit; long max_entries; bool ok; };
 static MsdaPlan msda_plan(const MsdaBins& bins, int B, int Nq, int nH, int L, int P) {
   MsdaPlan pl;
   pl.ntiles = bins.first_tile[L];
@@ -748,7 +762,10 @@ static MsdaPlan msda_plan(const MsdaBins& bins, int B, int Nq, int nH, int L, in
   pl.max_entries = (long)B * npts_b * 4;
   const long nbins = (long)B * pl.nloc;
   pl.nbins = (int)nbins;
-  pl.ok = nbins < (1L << 30) && Nq < (1 << 24) && pl.max_entries < (1L << 31) && (size_t)pl.nloc * 4 <= 60 * 1024 && B <= 65535;
+  pl.hsplit = (size_t)pl.nloc * 4 <= 60 * 1024 ? 1 : nH;                     // LDS histogram per workgroup: all heads, or one
+  const size_t hist_bytes = (size_t)(pl.hsplit == 1 ? pl.nloc : pl.ntiles) * 4;
+  pl.ok = nbins < (1L << 30) && Nq < (1 << 24) && pl.max_entries < (1L << 31) && hist_bytes <= 60 * 1024 && B <= 65535 &&
+          MSDA_SEG % (L * P) == 0 && (long)B * pl.nseg * pl.hsplit < (1L << 30);
   return pl;
 }
 static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
@@ -907,9 +924,9 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   msda_ws_layout(nbins, seg_ints, pl.max_entries, (char*)workspace, &ws);
   hipError_t he = hipMemsetAsync(ws.cnt, 0, (size_t)nbins * 4, s);
   if (he != hipSuccess) return (int)he;
-  const unsigned hgrid = msda_grid((long)pl.nseg * B, 1);
-  const size_t hsmem = (size_t)pl.nloc * 4;
-  msda_hist_k<false><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B);
+  const unsigned hgrid = msda_grid((long)pl.nseg * B * pl.hsplit, 1);
+  const size_t hsmem = (size_t)(pl.hsplit == 1 ? pl.nloc : pl.ntiles) * 4;
+  msda_hist_k<false><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B, pl.hsplit);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 2, s);
   msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
@@ -917,7 +934,7 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.nloc, pl.nseg, B);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 3, s);
-  msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B);
+  msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B, pl.hsplit);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 4, s);
   if (dtype == GE_F32)

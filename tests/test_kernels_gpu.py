@@ -225,6 +225,32 @@ def test_msda_fp32_fwd_bwd(dev, binned, shapes, monkeypatch):
     close_scaled(lg.grad, lc.grad, rel=2e-4, what='d loc')
 
 
+def test_msda_large_maps_use_per_head_histograms(dev):
+    """Value maps whose (heads x tiles) histogram exceeds one workgroup's LDS (native-resolution DDAD, config #4) take the
+    one-head-per-workgroup counting sort; same results as the oracle, and the workspace path is really taken."""
+    from gedepth_amd import hip, kernels
+    from gedepth_amd.kernels import ms_deform_attn
+    import ctypes
+    shapes = ((200, 320), (100, 160), (50, 80), (25, 40))                  # 2665 tiles x 8 heads x 4 B = 85 KB > 60 KB
+    value, loc, aw, go, shapes = _msda_inputs(3, B=1, Nq=90, shapes=shapes)
+    arr = (ctypes.c_int * 8)(*[v for hw in shapes for v in hw])
+    Nv = sum(h * w for h, w in shapes)
+    assert hip.lib().ge_msda_bwd_workspace(ctypes.cast(arr, ctypes.c_void_p), 1, Nv, 90, 8, 4, 8) > 0
+    vc, lc, ac = (t.clone().requires_grad_(True) for t in (value, loc, aw))
+    ref = O.msda_core(vc, shapes, lc, ac)
+    ref.backward(go)
+    vg, lg, ag = (t.to(dev).requires_grad_(True) for t in (value, loc, aw))
+    kernels.PROFILER.enable()
+    out = ms_deform_attn(vg, shapes, lg, ag)
+    out.backward(go.to(dev))
+    kernels.PROFILER.disable()
+    assert any(r['name'] == 'msda_drain_k' for r in kernels.PROFILER.msda_bwd_stages())       # the binned path ran
+    close(out, ref, what='out')
+    close_scaled(vg.grad, vc.grad, what='d value')
+    close_scaled(ag.grad, ac.grad, what='d attw')
+    close_scaled(lg.grad, lc.grad, rel=2e-4, what='d loc')
+
+
 def test_msda_golden(dev, golden):
     from gedepth_amd.kernels import ms_deform_attn
     g = golden('msda_core')
