@@ -5,7 +5,7 @@ hand-written kernel).  hipBLASLt's default heuristic picks poor macro
 model (M = 8 x 24640 ... 8 x 98560 tokens, K and N of 96 ... 768): PyTorch's TunableOp times the candidate solutions
 once and records the winner per shape.  The winners for the BASELINE workloads on gfx950 are committed in
 ``gedepth_amd/tuning/tunableop_gfx950.csv`` and only *looked up* at run time (no tuning, no start-up cost); shapes that
-are not in the file use the library default.  ``tools/tune_gemms.py`` regenerates the file.
+are not in the file use the library default.  ``tools/tune_tables.py`` regenerates both tables.
 """
 import os
 
