@@ -9,6 +9,8 @@ constant border) and are NOT pinned against cv2 output; OpenCV's warpAffine addi
 1/32 pixel, which is not reproduced.
 """
 import numpy as np
+import torch
+import torch.nn.functional as F
 
 _INTERP = ('nearest', 'bilinear')
 
@@ -57,7 +59,9 @@ def _resize_axis_bilinear(n_in, n_out):
 
 def imresize(img, size, return_scale=False, interpolation='bilinear'):
     """Resize to ``size`` = (w, h).  bilinear: half-pixel centres, edge replication, no antialiasing (cv2.INTER_LINEAR);
-    nearest: ``src = min(floor(dst * in / out), in - 1)`` (cv2.INTER_NEAREST)."""
+    nearest: ``src = min(floor(dst * in / out), in - 1)`` (cv2.INTER_NEAREST).  Both rules are exactly those of
+    ``F.interpolate(..., align_corners=False)`` / ``mode='nearest'``, whose CPU kernels do the work here (the numpy
+    formulation of the same rules, ``_imresize_numpy``, is kept for the tests)."""
     assert interpolation in _INTERP
     h, w = img.shape[:2]
     ow, oh = int(size[0]), int(size[1])
@@ -66,21 +70,29 @@ def imresize(img, size, return_scale=False, interpolation='bilinear'):
         xs = np.minimum(np.floor(np.arange(ow) * (w / ow)).astype(np.int64), w - 1)
         out = img[ys][:, xs]
     else:
-        src = img.astype(np.float32) if img.dtype != np.float64 else img
-        y0, y1, wy = _resize_axis_bilinear(h, oh)
-        x0, x1, wx = _resize_axis_bilinear(w, ow)
-        wy = wy.reshape((-1, 1) + (1,) * (img.ndim - 2))
-        wx = wx.reshape((1, -1) + (1,) * (img.ndim - 2))
-        top = src[y0][:, x0] * (1 - wx) + src[y0][:, x1] * wx
-        bot = src[y1][:, x0] * (1 - wx) + src[y1][:, x1] * wx
-        out = top * (1 - wy) + bot * wy
-        if img.dtype == np.uint8:
-            out = np.clip(np.rint(out), 0, 255).astype(np.uint8)
-        else:
-            out = out.astype(img.dtype)
+        t = torch.from_numpy(np.ascontiguousarray(img if img.ndim == 3 else img[..., None]))
+        t = t.permute(2, 0, 1)[None].to(torch.float64 if img.dtype == np.float64 else torch.float32)
+        o = F.interpolate(t, size=(oh, ow), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
+        if img.ndim == 2:
+            o = o[..., 0]
+        out = np.clip(np.rint(o), 0, 255).astype(np.uint8) if img.dtype == np.uint8 else o.astype(img.dtype)
     if return_scale:
         return out, ow / w, oh / h
     return out
+
+
+def _imresize_numpy(img, size):
+    """The bilinear rule of ``imresize`` spelled out in numpy (reference for the tests)."""
+    h, w = img.shape[:2]
+    ow, oh = int(size[0]), int(size[1])
+    src = img.astype(np.float32) if img.dtype != np.float64 else img
+    y0, y1, wy = _resize_axis_bilinear(h, oh)
+    x0, x1, wx = _resize_axis_bilinear(w, ow)
+    wy = wy.reshape((-1, 1) + (1,) * (img.ndim - 2))
+    wx = wx.reshape((1, -1) + (1,) * (img.ndim - 2))
+    top = src[y0][:, x0] * (1 - wx) + src[y0][:, x1] * wx
+    bot = src[y1][:, x0] * (1 - wx) + src[y1][:, x1] * wx
+    return (top * (1 - wy) + bot * wy).astype(img.dtype if img.dtype != np.uint8 else np.float32)
 
 
 def imrescale(img, scale, return_scale=False, interpolation='bilinear'):
@@ -90,28 +102,73 @@ def imrescale(img, scale, return_scale=False, interpolation='bilinear'):
     return (out, scale_factor) if return_scale else out
 
 
-def imrotate(img, angle, center=None, scale=1.0, border_value=0, interpolation='bilinear', auto_bound=False):
-    """Rotate clockwise by ``angle`` degrees about ``center`` (default: the image centre), output size = input size:
-    ``cv2.warpAffine(img, cv2.getRotationMatrix2D(center, -angle, scale), (w, h), borderValue=border_value)``."""
-    assert interpolation in _INTERP
-    if auto_bound:
-        raise NotImplementedError('auto_bound is not used on the GEDepth path')
-    h, w = img.shape[:2]
+def _inverse_rotation(h, w, angle, center, scale):
+    """2x2 matrix and offset of dst -> src for cv2.getRotationMatrix2D(center, -angle, scale) + warpAffine (float64)."""
     cx, cy = ((w - 1) * 0.5, (h - 1) * 0.5) if center is None else center
     a = np.deg2rad(-angle)
     alpha, beta = scale * np.cos(a), scale * np.sin(a)
     m = np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
-    # dst(x, y) = src(M^-1 (x, y)): invert the 2x3 affine
     det = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
-    inv = np.array([[m[1, 1], -m[0, 1]], [-m[1, 0], m[0, 0]]]) / det
-    off = -inv @ m[:, 2]
-    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
-    sx = inv[0, 0] * xs + inv[0, 1] * ys + off[0]
-    sy = inv[1, 0] * xs + inv[1, 1] * ys + off[1]
+    inv = np.array([[m[1, 1], -m[0, 1]], [-m[1, 0], m[0, 0]]]) / det              # dst(x, y) = src(M^-1 (x, y))
+    return inv, -inv @ m[:, 2]
+
+
+def _rotation_source_coords(h, w, angle, center, scale, dtype=np.float64):
+    """Source (x, y) of every destination pixel."""
+    inv, off = _inverse_rotation(h, w, angle, center, scale)
+    inv, off = inv.astype(dtype), off.astype(dtype)
+    xs, ys = np.arange(w, dtype=dtype)[None, :], np.arange(h, dtype=dtype)[:, None]
+    return inv[0, 0] * xs + inv[0, 1] * ys + off[0], inv[1, 0] * xs + inv[1, 1] * ys + off[1]
+
+
+_GRID_CACHE = {}
+
+
+def _rotation_grid(h, w, angle, center, scale):
+    """Normalised (align_corners=True) sampling grid of a rotation; the image, the depth map and the slope classes of one
+    sample are rotated with the same parameters, so the last grid is kept."""
+    key = (h, w, angle, center, scale)
+    if key not in _GRID_CACHE:
+        sx, sy = _rotation_source_coords(h, w, angle, center, scale, np.float32)   # matrix in float64, the map in float32
+        grid = np.empty((1, h, w, 2), dtype=np.float32)
+        grid[0, :, :, 0] = sx * (2.0 / (w - 1)) - 1.0
+        grid[0, :, :, 1] = sy * (2.0 / (h - 1)) - 1.0
+        _GRID_CACHE.clear()
+        _GRID_CACHE[key] = torch.from_numpy(grid)
+    return _GRID_CACHE[key]
+
+
+def imrotate(img, angle, center=None, scale=1.0, border_value=0, interpolation='bilinear', auto_bound=False):
+    """Rotate clockwise by ``angle`` degrees about ``center`` (default: the image centre), output size = input size:
+    ``cv2.warpAffine(img, cv2.getRotationMatrix2D(center, -angle, scale), (w, h), borderValue=border_value)`` — inverse
+    mapping, constant border.  The sampling itself runs in ``F.grid_sample`` (align_corners=True puts its normalised grid on
+    pixel centres; zero padding after subtracting the border value gives the constant border); ``_imrotate_numpy`` is the
+    same rule in numpy, kept for the tests."""
+    assert interpolation in _INTERP
+    if auto_bound:
+        raise NotImplementedError('auto_bound is not used on the GEDepth path')
+    h, w = img.shape[:2]
+    if h < 2 or w < 2:
+        return _imrotate_numpy(img, angle, center, scale, border_value, interpolation)
+    grid = _rotation_grid(h, w, float(angle), None if center is None else tuple(center), float(scale))
+    src = img[..., None] if img.ndim == 2 else img
+    border = np.broadcast_to(np.asarray(border_value, dtype=np.float32), (src.shape[2],)).reshape(1, -1, 1, 1)
+    t = torch.from_numpy(np.ascontiguousarray(src)).permute(2, 0, 1)[None].float() - torch.from_numpy(border.copy())
+    o = F.grid_sample(t, grid, mode=interpolation, padding_mode='zeros', align_corners=True) + torch.from_numpy(border.copy())
+    out = o[0].permute(1, 2, 0).numpy()
+    if img.dtype == np.uint8:
+        out = np.clip(np.rint(out), 0, 255)
+    out = out.astype(img.dtype)
+    return out[..., 0] if img.ndim == 2 else out
+
+
+def _imrotate_numpy(img, angle, center=None, scale=1.0, border_value=0, interpolation='bilinear'):
+    h, w = img.shape[:2]
+    sx, sy = _rotation_source_coords(h, w, angle, center, scale)
+    sx, sy = np.broadcast_to(sx, (h, w)), np.broadcast_to(sy, (h, w))
     squeeze = img.ndim == 2
     src = img[..., None] if squeeze else img
-    border = np.broadcast_to(np.asarray(border_value, dtype=np.float64), (src.shape[2],)) if np.ndim(border_value) else \
-        np.full((src.shape[2],), float(border_value))
+    border = np.broadcast_to(np.asarray(border_value, dtype=np.float64), (src.shape[2],))
 
     def fetch(yi, xi):
         inside = (yi >= 0) & (yi < h) & (xi >= 0) & (xi < w)

@@ -42,6 +42,12 @@ def test_image_ops_follow_the_documented_sampling_rules():
         assert np.allclose(I.imresize(img, size), ref, atol=1e-6)
         refn = F.interpolate(t, size=(size[1], size[0]), mode='nearest')[0].permute(1, 2, 0).numpy()
         assert np.array_equal(I.imresize(img, size, interpolation='nearest'), refn)
+        assert np.allclose(I._imresize_numpy(img, size), ref, atol=1e-6)                 # the rule, spelled out
+    for angle in (2.5, -17.0, 90.0):                                                      # grid_sample path == numpy rule
+        for mode, border in (('bilinear', 0), ('nearest', 255)):
+            a = I.imrotate(img, angle, border_value=border, interpolation=mode)
+            b = I._imrotate_numpy(img, angle, border_value=border, interpolation=mode)
+            assert (np.abs(a - b) > 1e-3).mean() <= (0.0 if mode == 'bilinear' else 0.02)  # nearest: ties may round either way
     assert I.rescale_size((1216, 352), 0.5) == (608, 176)
     assert I.rescale_size((1216, 352), (2000, 500)) == (int(1216 * 500 / 352 + 0.5), 500)
     sq = g.random((9, 9)).astype(np.float32)
