@@ -183,3 +183,29 @@ def test_official_swin_checkpoint_loads_like_the_reference(golden):
     assert checked >= 20
     w = sd['patch_embed.projection.weight']
     assert w.shape[1] == 4 and float(w[:, 3].abs().max()) == 0.0
+
+
+def test_tuning_tables_are_lookup_only(monkeypatch, tmp_path):
+    """The committed library-selection tables: the GEMM table parses (validators + >= 60 shapes, incl. the batched split-K
+    weight gradients), the MIOpen find-db is seeded into a content-keyed scratch copy, and 'off' disables TunableOp."""
+    import csv
+    from gedepth_amd.mmrt import tuning
+    rows = list(csv.reader(open(tuning.GEMM_TABLE)))
+    assert any(r[0] == 'Validator' and r[1] == 'GCN_ARCH_NAME' and r[2].startswith('gfx950') for r in rows)
+    shapes = [r for r in rows if r[0] != 'Validator']
+    assert len(shapes) >= 60 and any('StridedBatched' in r[0] for r in shapes)
+    monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
+    monkeypatch.setenv('TMPDIR', str(tmp_path))
+    import tempfile
+    tempfile.tempdir = None
+    try:
+        assert tuning.use_miopen_find_db() is True
+        dst = os.environ['MIOPEN_USER_DB_PATH']
+        assert dst.startswith(str(tmp_path)) and sorted(os.listdir(dst)) == sorted(
+            f for f in os.listdir(tuning.MIOPEN_DB) if f.endswith('db.txt'))
+    finally:
+        tempfile.tempdir = None
+        os.environ.pop('MIOPEN_USER_DB_PATH', None)
+    assert tuning.use_tuned_gemms('off') is False
+    with pytest.raises(ValueError):
+        tuning.use_tuned_gemms('sometimes')
