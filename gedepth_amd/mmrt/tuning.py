@@ -16,12 +16,15 @@ MIOPEN_DB = os.path.join(os.path.dirname(_HERE), 'tuning', 'miopen')
 
 def use_tuned_gemms(mode='load', path=GEMM_TABLE):
     """mode: 'off' | 'load' (look up the committed table) | 'tune' (time unseen shapes and append them on exit)."""
+    if mode not in ('off', 'load', 'tune'):
+        raise ValueError(f'gemm tuning mode {mode!r}')
+    import torch
     import torch.cuda.tunable as tunable
+    if not torch.cuda.is_available():                  # TunableOp state lives in the HIP context
+        return False
     if mode == 'off':
         tunable.enable(False)
         return False
-    if mode not in ('load', 'tune'):
-        raise ValueError(f'gemm tuning mode {mode!r}')
     tunable.enable(True)
     tunable.tuning_enable(mode == 'tune')
     tunable.set_filename(path, insert_device_ordinal=False)
