@@ -34,7 +34,10 @@ def parse():
     ap.add_argument('--width', type=int, default=1120)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true', help='skip the second (HIP-event profiled) pass')
+    ap.add_argument('--profile-steps', type=int, default=5, help='steps of the separate per-kernel timing pass')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the extra reference-precision (fp32) measurement at N=1')
+    ap.add_argument('--fp32-steps', type=int, default=5)
     ap.add_argument('--gemm-tuning', default='load', choices=['off', 'load', 'tune'],
                     help='hipBLASLt/rocBLAS solution table for the Linear layers (gedepth_amd/mmrt/tuning.py)')
     ap.add_argument('--cudnn-benchmark', type=int, default=-1,
@@ -43,15 +46,28 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(cfg_name, H, W):
-    """The CPU oracle (oracle/gedepth_oracle.py, a port validated against reference-generated fixtures) timed on the
-    host cores: one full training step (fwd + losses + bwd + clip + AdamW) on ONE synthetic image."""
+    """the CPU oracle (oracle/gedepth_oracle.py, a port pinned to reference-generated fixtures) on the
+    GPU box's host cores, fp32, batch 1: 1 warm-up + 3 timed full training steps (fwd + losses + bwd + clip 35 + AdamW)
+    and 1 + 3 eval forwards.  Threads: min(host cores, 32) — the op sizes of one image do not scale further (256
+    threads measured 27x slower); both numbers are reported."""
     from gedepth_amd.depth.datasets.synthetic import synthetic_batch
     from oracle import gedepth_oracle as O
     from oracle.fill import fill_state_dict
     from gedepth_amd.depth.models import build_depther
     from gedepth_amd.mmrt.config import Config
-    cores = min(os.cpu_count() or 1, 32)        # more threads only add synchronisation overhead for these op sizes
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 32)
     torch.set_num_threads(cores)
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', cfg_name))
     cfg.model.pretrained = None
@@ -64,16 +80,32 @@ def cpu_baseline(cfg_name, H, W):
               if v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))]
     opt = torch.optim.AdamW(leaves, lr=1e-4, weight_decay=0.01)
     b = synthetic_batch(1, H, W, seed=1234)
-    t0 = time.perf_counter()
-    losses, _ = O.forward_train(b['img'], b['depth_gt'], b['pe_k_gt'], P, arch, train_bn=True)
-    loss, _ = O.parse_losses(losses)
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(leaves, 35.0)
-    opt.step()
-    dt = time.perf_counter() - t0
-    return dict(value=round(1.0 / dt, 5), unit='img/s', cores=cores, kind='port',
-                sample=f'1 training step (fwd+loss+bwd+clip+AdamW) on 1 image {H}x{W}, fp32, torch {torch.__version__} CPU, '
-                       f'{dt:.1f} s, no warm-up')
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        losses, _ = O.forward_train(b['img'], b['depth_gt'], b['pe_k_gt'], P, arch, train_bn=True)
+        loss = sum(v.mean() for k, v in losses.items() if 'loss' in k)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 35.0)
+        opt.step()
+
+    def eval_step():
+        with torch.no_grad():
+            O.encode_decode(b['img'], P, arch)
+
+    def timed(fn, warm=1, n=3):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t0) / n
+    dt_train = timed(train_step)
+    dt_eval = timed(eval_step)
+    return dict(value=round(1.0 / dt_train, 5), unit='img/s', cores=cores, host_cores=host_cores, cpu=_cpu_model(), kind='port',
+                eval_value=round(1.0 / dt_eval, 5),
+                sample=f'1 warm-up + 3 timed training steps (fwd+loss+bwd+clip+AdamW, {dt_train:.2f} s each) and 1 + 3 eval forwards '
+                       f'({dt_eval:.2f} s each) on 1 image {H}x{W}, fp32, torch {torch.__version__} CPU, {cores} threads')
 
 
 def pmc_traffic(kernel):
@@ -90,28 +122,26 @@ def pmc_traffic(kernel):
     return None
 
 
-def main():
-    args = parse()
-    from gedepth_amd.mmrt.ddp import FlatDDP, init_dist
-    rank, local, world = init_dist('nccl')
-    assert torch.cuda.is_available(), 'bench.py measures the MI355X path; there is no CPU fallback'
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
-    from gedepth_amd.mmrt.tuning import use_miopen_find_db, use_tuned_gemms
-    have_db = use_miopen_find_db() if args.cudnn_benchmark != 0 else False
-    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark == 1 or (args.cudnn_benchmark == -1 and have_db))
-    use_tuned_gemms(args.gemm_tuning)
+def respawn_under_launcher(args):
+    """``python bench.py --gpus N`` without a launcher: re-exec under torch.distributed.run (one rank per GPU, RCCL),
+    the way the reference launches training (tools/dist_train.sh:7-9)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
-    from gedepth_amd import hip, kernels
+
+def build_job(args, cfg, dev, rank, dtype):
+    """model + optimizer + DDP wrapper + resident synthetic batch + the step closure for one precision."""
     from gedepth_amd.depth.datasets.synthetic import synthetic_batch
     from gedepth_amd.depth.models import build_depther
-    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.ddp import FlatDDP
     from gedepth_amd.mmrt.optim import build_optimizer
-    hip.lib()
-
-    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', args.config))
-    cfg.model.pretrained = None                             # random-init weights of the named architecture
     per_gpu = args.batch or cfg.data.samples_per_gpu
     torch.manual_seed(1234)
     model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
@@ -120,7 +150,9 @@ def main():
     optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
     ddp = FlatDDP(model, optimizer.arena)
     batch = synthetic_batch(per_gpu, args.height, args.width, seed=1234 + rank, device=dev)
-    amp = args.dtype == 'bf16'
+    if 'ddad' in args.config:                                # per-sample camera heights (loading.py:923-932)
+        batch['height'] = torch.full((per_gpu,), 1.56, device=dev)
+    amp = dtype == 'bf16'
 
     def step():
         optimizer.zero_grad()
@@ -130,28 +162,67 @@ def main():
         ddp.finish()
         optimizer.step()
         return out
+    return step, per_gpu, optimizer
 
-    def fence():
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+def fence():
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_steps(step, warmup, steps, dev, world):
+    for _ in range(warmup):
         out = step()
     fence()
-    if not args.no_kernel_timing:
-        kernels.PROFILER.enable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    kernels.PROFILER.disable()
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
+    return t.item(), out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn_under_launcher(args)
+    from gedepth_amd.mmrt.ddp import init_dist
+    rank, local, world = init_dist('nccl')
+    assert torch.cuda.is_available(), 'bench.py measures the MI355X path; there is no CPU fallback'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    from gedepth_amd.mmrt.tuning import use_miopen_find_db, use_tuned_gemms
+    have_db = use_miopen_find_db() if args.cudnn_benchmark != 0 else False
+    torch.backends.cudnn.benchmark = bool(args.cudnn_benchmark == 1 or (args.cudnn_benchmark == -1 and have_db))
+    use_tuned_gemms(args.gemm_tuning)
+
+    from gedepth_amd import hip, kernels
+    from gedepth_amd.mmrt.config import Config
+    hip.lib()
+
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', args.config))
+    cfg.model.pretrained = None                             # random-init weights of the named architecture
+    step, per_gpu, optimizer = build_job(args, cfg, dev, rank, args.dtype)
+
+    # ---- pass 1: the headline number; the per-kernel event profiler is OFF inside the timed region
+    elapsed, out = timed_steps(step, args.warmup, args.steps, dev, world)
     loss = out['log_vars']['loss']
+    # ---- pass 2: the same steps again with HIP events around every hand-written kernel (roofline object)
+    prof, stages = [], []
+    if not args.no_kernel_timing and args.profile_steps > 0:
+        kernels.PROFILER.enable()
+        for _ in range(args.profile_steps):
+            step()
+        fence()
+        kernels.PROFILER.disable()
+        prof = kernels.PROFILER.summary()
+        stages = kernels.PROFILER.msda_bwd_stages()
+    prof_ms_per_step = sum(r['total_ms'] for r in prof) / max(1, args.profile_steps)
 
     if rank == 0:
         total_imgs = per_gpu * world * args.steps
@@ -166,23 +237,38 @@ def main():
                        'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'last_loss': round(float(loss), 5),
                        'params': int(optimizer.arena.numel)},
         }
-        prof = kernels.PROFILER.summary()
         if prof:
-            # the MSDA backward is five kernels behind one entry point: rank its kernels individually (timed by HIP events
+            # the MSDA backward is several kernels behind one entry point: rank its kernels individually (timed by HIP events
             # inside the library), so that `roofline` is about ONE kernel whose name rocprofv3 reports too
-            stages = kernels.PROFILER.msda_bwd_stages()
             single = [r for r in prof if not (stages and r['name'].startswith('msda_bwd['))] + stages
             dom = max(single, key=lambda r: r['total_ms'])
             gbs = dom['bytes_per_launch'] / (dom['avg_us'] * 1e-6) / 1e9
             res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
                                'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
                                'avg_us': round(dom['avg_us'], 2), 'launches': dom['launches'],
-                               'algorithmic_bytes_per_launch': int(dom['bytes_per_launch'])}
+                               'algorithmic_bytes_per_launch': int(dom['bytes_per_launch']),
+                               'timed': f'HIP events on the launch stream, separate pass of {args.profile_steps} steps after the timed region'}
             res['roofline']['traffic'] = pmc_traffic(dom['name'])
+            step_ms = 1e3 * elapsed / args.steps
             res['kernels'] = [{'name': r['name'], 'launches': r['launches'], 'avg_us': round(r['avg_us'], 2),
                                'GBps': round(r['bytes_per_launch'] / (r['avg_us'] * 1e-6) / 1e9, 1),
-                               'share_of_step': round(r['total_ms'] / (1e3 * elapsed), 4)} for r in
+                               'share_of_step': round(r['total_ms'] / args.profile_steps / step_ms, 4)} for r in
                               sorted(prof + stages, key=lambda r: -r['total_ms'])[:24]]
+            res['own_kernels_ms_per_step'] = round(prof_ms_per_step, 2)
+    del step, optimizer, out
+    torch.cuda.empty_cache()
+
+    # ---- reference-precision (fp32, exact-fp32 attention off: library fp32 GEMM/conv + the same HIP kernels) line at N=1
+    if world == 1 and args.dtype != 'fp32' and not args.no_fp32:
+        step32, _, opt32 = build_job(args, cfg, dev, rank, 'fp32')
+        e32, o32 = timed_steps(step32, 2, args.fp32_steps, dev, world)
+        if rank == 0:
+            res['fp32'] = {'value': round(per_gpu * args.fp32_steps / e32, 3), 'unit': 'img/s', 'ms_per_step': round(1e3 * e32 / args.fp32_steps, 3),
+                           'steps': args.fp32_steps, 'warmup': 2, 'dtype': 'fp32', 'last_loss': round(float(o32['log_vars']['loss']), 5),
+                           'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision)'}
+        del step32, opt32, o32
+        torch.cuda.empty_cache()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.config, args.height, args.width)
         print(json.dumps(res), flush=True)

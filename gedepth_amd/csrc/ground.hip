@@ -431,6 +431,32 @@ extern "C" int ge_slope_class(const double* gt, const float* pe, double cam_heig
   return GE_OK;
 }
 
+// DDAD variant (tools/preprocess_data_ddad.py:47-51,68-78): gt is the float32 depth of the .npz, pe stays float64,
+// a = -h/pe in float64, b = h/gt in FLOAT32 (Python scalar / float32 array), k = b + a in float64, truncation.
+__global__ void __launch_bounds__(256) slope_class_ddad_k(const float* __restrict__ gt, const double* __restrict__ pe, double hcam,
+                                                          int16_t* __restrict__ cls, long total) {
+  const double RAD2DEG = 57.29577951308232;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const float g = gt[idx];
+    const double a = (-hcam) / pe[idx];
+    const float b = (float)hcam / g;
+    const double k = (double)b + a;
+    double r = trunc(atan(k) * RAD2DEG);
+    if (r > 5.0) r = 5.0;
+    if (r < -5.0) r = -5.0;
+    int16_t out = (int16_t)r;
+    if (!(r == r)) out = 0;
+    if (g == 0.f) out = 255;
+    cls[idx] = out;
+  }
+}
+extern "C" int ge_slope_class_ddad(const float* gt, const double* pe, double cam_height, int16_t* cls, int H, int W, void* stream) {
+  if (!gt || !pe || !cls || H <= 0 || W <= 0) return GE_ERR_BAD_ARG;
+  slope_class_ddad_k<<<ge_blocks((long)H * W, 256, 65536), 256, 0, ge_stream(stream)>>>(gt, pe, cam_height, cls, (long)H * W);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
 __global__ void __launch_bounds__(256) pe_channels_k(const float* __restrict__ raw, float* __restrict__ norm, float depth_scale, long n) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
     float v = raw[idx];

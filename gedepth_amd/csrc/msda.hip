@@ -820,6 +820,21 @@ extern "C" size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, in
   return msda_ws_layout(pl.nbins, (long)B * pl.nseg * pl.nloc, pl.max_entries, nullptr, nullptr);
 }
 
+// Which backward path ge_msda_bwd takes for a geometry (introspection for tests / DESIGN tables; no device work):
+// out[0] = 1 binned (workspace) path available, out[1] = histogram split (1 = all heads per workgroup, nH = one head per
+// workgroup: maps too large for one LDS histogram, e.g. 1216 x 1936), out[2] = value tiles, out[3] = bins.
+extern "C" int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int* out4) {
+  MsdaLevels lv;
+  if (!spatial_hw || !out4) return GE_ERR_BAD_ARG;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  MsdaBins bins;
+  msda_bins(lv, L, bins);
+  const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
+  out4[0] = pl.ok ? 1 : 0; out4[1] = pl.hsplit; out4[2] = pl.ntiles; out4[3] = pl.nbins;
+  return GE_OK;
+}
+
 // ---- optional per-kernel timing of the composite backward: a measurement aid for bench.py (its roofline object needs
 // the duration of ONE kernel, and HIP events recorded by the caller can only bracket the whole entry point).  Off by
 // default; when off the entry point records nothing and never synchronises.

@@ -25,6 +25,7 @@ SIGNATURES = {
     'ge_msda_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_workspace': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_bwd_plan': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_timing': (_i, [_i]),
     'ge_msda_bwd_timing_read': (_i, [_i, _vp, _vp, _vp, _i]),
     'ge_msda_prep_fwd': (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     'ge_depth_fuse_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_ground_plane': (_i, [_vp, _d, _vp, _vp, _i, _i, _vp]),
     'ge_slope_class': (_i, [_vp, _vp, _d, _i, _vp, _i, _i, _vp]),
+    'ge_slope_class_ddad': (_i, [_vp, _vp, _d, _vp, _i, _i, _vp]),
     'ge_pe_channels': (_i, [_vp, _vp, _f, _l, _vp]),
     'ge_silog_stats': (_i, [_vp, _vp, _f, _vp, _l, _vp]),
     'ge_silog_bwd': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _l, _vp]),

@@ -719,6 +719,17 @@ def slope_class(gt_f64, pe_f32, cam_height=1.65, mode='round'):
     return cls
 
 
+def slope_class_ddad(gt_f32, pe_f64, cam_height):
+    """DDAD slope classes with the reference script's dtypes (gt float32, pe float64, truncation); int16 (H,W)."""
+    gt_f32 = _c(gt_f32.to(_f32))
+    pe_f64 = _c(pe_f64.to(torch.float64))
+    H, W = gt_f32.shape
+    cls = torch.empty(H, W, device=gt_f32.device, dtype=torch.int16)
+    hip.check(hip.lib().ge_slope_class_ddad(hip.ptr(gt_f32), hip.ptr(pe_f64), float(cam_height), hip.ptr(cls), H, W,
+                                            hip.stream()), 'ge_slope_class_ddad')
+    return cls
+
+
 def pe_channels(raw, depth_scale=200.0):
     raw = _c(raw.to(_f32))
     norm = torch.empty_like(raw)

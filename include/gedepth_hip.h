@@ -81,6 +81,9 @@ int ge_msda_fwd(const void* value, const int* spatial_hw, const float* loc, cons
  * (one integer atomic per tap, tiles accumulated in registers); with workspace == NULL the scatter falls back to
  * fp32 atomic bursts straight into d_value. */
 size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P);
+/* Introspection (no device work): out4 = {binned path available, histogram split (1 = all heads per workgroup,
+ * nH = one head per workgroup for maps whose tile count exceeds one LDS histogram), value tiles, bins}. */
+int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int* out4);
 int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw,
                 const void* d_out, float* d_value, float* d_loc, float* d_attw,
                 void* workspace, size_t workspace_bytes,
@@ -239,6 +242,9 @@ int ge_depth_fuse_bwd(const float* c, const float* y_ds, const float* d_out,
  * ge_slope_class: k = h/gt + f32(-h)/pe; round (mode 0, KITTI :59-63,83-89) or trunc (mode 1, DDAD
  *   tools/preprocess_data_ddad.py:78) of deg(atan k), clamp to [-5,5], 255 where gt==0.
  *   gt f64 (H,W) [uint16 PNG / 256], pe f32 (H,W) -> cls int16 (H,W).
+ * ge_slope_class_ddad: the DDAD script's own dtypes (tools/preprocess_data_ddad.py:47-51,68-78): gt f32 (the .npz
+ *   depth), pe f64 (the map of :35-41, numerator RT[2] without a height term); a = -h/pe in f64, b = h/gt in F32,
+ *   k = b + a in f64, truncation (astype(int64)), clamp, 255 where gt==0.
  * ge_pe_channels: loader-side filtering + normalisation (loading.py:397-403, transforms.py:40-48):
  *   raw f32 -> norm f32 (>200 -> 0, <0 -> 0, then / depth_scale where > 0).
  */
@@ -246,6 +252,8 @@ int ge_ground_plane(const double* rinv_row2, double num, double* pe_f64, float* 
                     void* stream);
 int ge_slope_class(const double* gt, const float* pe, double cam_height, int mode, int16_t* cls,
                    int H, int W, void* stream);
+int ge_slope_class_ddad(const float* gt, const double* pe, double cam_height, int16_t* cls, int H, int W,
+                        void* stream);
 int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -107,7 +107,7 @@ def shift_window_msa(x, hw, P, prefix, num_heads, shift):
     Hp, Wp = x.shape[1], x.shape[2]
     if shift > 0:
         x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
-        mask = shift_mask(Hp, Wp, ws, shift)
+        mask = shift_mask(Hp, Wp, ws, shift).to(x.dtype)
     else:
         mask = None
     xw = window_partition(x, ws).view(-1, ws * ws, C)
@@ -183,8 +183,9 @@ def backbone(img, P, cfg, train_bn=False, prefix='backbone'):
 
 
 # =================================================================================== neck
-def sine_positional_encoding(B, H, W, num_feats=256, temperature=10000):
-    """SinePositionalEncoding.forward on an all-false mask, depth/utils/position_encoding.py:54-89."""
+def sine_positional_encoding(B, H, W, num_feats=256, temperature=10000, dtype=torch.float32):
+    """SinePositionalEncoding.forward on an all-false mask, depth/utils/position_encoding.py:54-89.  Always evaluated
+    in fp32 like the reference (an input-independent constant); ``dtype`` only casts the result (float64 oracle mode)."""
     not_mask = torch.ones(B, H, W, dtype=torch.int)
     y_embed = not_mask.cumsum(1, dtype=torch.float32)
     x_embed = not_mask.cumsum(2, dtype=torch.float32)
@@ -194,7 +195,7 @@ def sine_positional_encoding(B, H, W, num_feats=256, temperature=10000):
     pos_y = y_embed[:, :, :, None] / dim_t
     pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
     pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
-    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2).to(dtype)
 
 
 def msda_core(value, spatial_shapes, sampling_locations, attention_weights):
@@ -254,14 +255,14 @@ def conv_module(x, P, prefix, train_bn, padding=0, norm=True, act='relu'):
     return x
 
 
-def hahi_reference_points(spatial_shapes, B):
+def hahi_reference_points(spatial_shapes, B, dtype=torch.float32):
     """HAHIHeteroNeck.get_reference_points with valid_ratios == 1, necks/hahi.py:220-233."""
     pts = []
     for (h, w) in spatial_shapes:
         ry, rx = torch.meshgrid(torch.linspace(0.5, h - 0.5, h), torch.linspace(0.5, w - 0.5, w), indexing='ij')
         pts.append(torch.stack((rx.reshape(-1)[None] / w, ry.reshape(-1)[None] / h), -1))
     ref = torch.cat(pts, 1)
-    return ref[:, :, None].repeat(B, 1, len(spatial_shapes), 1)
+    return ref[:, :, None].repeat(B, 1, len(spatial_shapes), 1).to(dtype)
 
 
 def hahi_neck(inputs, P, train_bn=False, prefix='neck', embed=512):
@@ -273,17 +274,17 @@ def hahi_neck(inputs, P, train_bn=False, prefix='neck', embed=512):
     for i, ft in enumerate(feats_trans):
         _, _, h, w = ft.shape
         spatial_shapes.append((h, w))
-        pos = sine_positional_encoding(B, h, w).flatten(2).transpose(1, 2)
+        pos = sine_positional_encoding(B, h, w, dtype=ft.dtype).flatten(2).transpose(1, 2)
         poss.append(pos + P[prefix + '.level_embed'][i].view(1, 1, -1))
         srcs.append(conv_module(ft, P, f'{prefix}.trans_proj.{i}', train_bn).flatten(2).transpose(1, 2))
     src_flatten = torch.cat(srcs, 1)
     pos_flatten = torch.cat(poss, 1)
-    ref = hahi_reference_points(spatial_shapes, B)
+    ref = hahi_reference_points(spatial_shapes, B, feat_conv.dtype)
     src = msda_module(src_flatten, None, pos_flatten, ref, spatial_shapes, P, prefix + '.self_attn')
     conv_skip = conv_module(feat_conv, P, f'{prefix}.conv_proj.0', train_bn)
     bs, c, h, w = conv_skip.shape
     query = conv_skip.flatten(2).transpose(1, 2)
-    query_embed = sine_positional_encoding(B, h, w).flatten(2).transpose(1, 2)
+    query_embed = sine_positional_encoding(B, h, w, dtype=query.dtype).flatten(2).transpose(1, 2)
     rp = F.linear(query_embed, P[prefix + '.reference_points.weight'], P[prefix + '.reference_points.bias']).sigmoid()
     rp = rp[:, :, None].repeat(1, 1, len(spatial_shapes), 1)
     fusion = msda_module(query, src, query_embed, rp, spatial_shapes, P, prefix + '.multi_att')
@@ -332,7 +333,7 @@ def dynamic_pe(logits_lr, y, pe_raw, height=1.65, depth_scale=200.0):
     pe = pe_raw.unsqueeze(1)
     logits = F.interpolate(logits_lr, size=[pe.shape[2], pe.shape[3]], mode='bilinear')
     k = F.softmax(logits, dim=1)
-    indices = torch.linspace(-5, 5, 11).view(1, 11, 1, 1)
+    indices = torch.linspace(-5, 5, 11).view(1, 11, 1, 1).to(logits.dtype)
     k = torch.sum(k * indices, dim=1).unsqueeze(1)
     k = torch.tan(torch.deg2rad(k))
     h = height.view(-1, 1, 1, 1) if torch.is_tensor(height) else height
@@ -459,6 +460,38 @@ def slope_class(gt, pe, cam_height=1.65, mode='round'):
     k[k < -5] = -5
     k[gt == 0] = 255
     return k
+
+
+def ground_plane_ddad(intrinsics, camera_pose, lidar_pose, height_img, width_img):
+    """tools/preprocess_data_ddad.py:29-41: A = K4 @ inv(camera_pose) @ lidar_pose; the plane is the lidar frame's z = 0
+    (numerator RT[2], NO camera-height term — the per-camera heights enter only in find_k / dynamic_pe).  float64."""
+    K4 = np.eye(4)
+    K4[:3, :3] = np.asarray(intrinsics, dtype=np.float64)
+    A = K4 @ np.linalg.inv(np.asarray(camera_pose, dtype=np.float64)) @ np.asarray(lidar_pose, dtype=np.float64)
+    Rinv = np.linalg.inv(A[:3, :3])
+    RT = Rinv @ A[0:3, 3]
+    u, v = np.meshgrid(range(width_img), range(height_img), indexing='xy')
+    pe = RT[2] / (Rinv[2, 0] * u + Rinv[2, 1] * v + Rinv[2, 2])
+    return pe, Rinv[2].copy(), float(RT[2])
+
+
+def slope_class_ddad(gt, pe, cam_height):
+    """tools/preprocess_data_ddad.py:47-51,68-78: gt is the float32 depth of the .npz, pe the float64 map, h a Python
+    float: ``a = -h/pe`` (float64), ``b = h/gt`` (float32: scalar / float32 array), ``k = b + a`` (float64),
+    ``rad2deg(arctan(k)).astype(int64)`` (truncation), clip to +-5, 255 where gt == 0.  -> int64 map."""
+    gt = np.asarray(gt, dtype=np.float32)
+    pe = np.asarray(pe, dtype=np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        a = -cam_height / pe
+        b = np.float32(cam_height) / gt
+        k = np.rad2deg(np.arctan(b + a)).astype(np.int64)
+    k[k > 5] = 5
+    k[k < -5] = -5
+    k[gt == 0] = 255
+    return k
+
+
+DDAD_CAMERA_HEIGHTS = {'CAMERA_01': 1.56, 'CAMERA_05': 1.57, 'CAMERA_06': 1.53, 'CAMERA_09': 1.53}   # preprocess_data_ddad.py:68-75
 
 
 def loader_pe_channels(pe, depth_scale=200.0):

@@ -1,0 +1,60 @@
+"""Worker of tests/test_model_gpu.py::test_rccl_gradient_exchange_single_rank (run as a subprocess with GE_DDP_FORCE=1):
+two training steps with FlatDDP active on the nccl (RCCL) backend, world size 1, against the same two steps without DDP."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(active):
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.depth.models import build_depther
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.ddp import FlatDDP
+    from gedepth_amd.mmrt.optim import build_optimizer
+    os.environ['GE_DDP_FORCE'] = '1' if active else '0'
+    dev = torch.device('cuda', 0)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_a.py'))
+    cfg.model.pretrained = None
+    cfg.model.backbone.drop_path_rate = 0.0
+    torch.manual_seed(5)
+    model = build_depther(cfg.model)
+    model.init_weights()
+    model.neck.multi_att.dropout.p = 0.0
+    model.neck.self_attn.dropout.p = 0.0
+    model = model.to(dev).train()
+    optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    ddp = FlatDDP(model, optimizer.arena, bucket_mb=8)
+    assert ddp.active == active and (not active or (ddp.backend == 'nccl' and len(ddp.buckets) > 2)), (ddp.active, ddp.backend)
+    batch = synthetic_batch(2, 128, 160, seed=21, device=dev, valid_fraction=0.3)
+    losses = []
+    for _ in range(2):
+        optimizer.zero_grad()
+        out = ddp.train_step(batch, optimizer)
+        out['loss'].backward()
+        ddp.finish()
+        optimizer.step()
+        losses.append(float(out['log_vars']['loss']))
+    torch.cuda.synchronize()
+    return losses, optimizer.arena.flat_param.detach().clone()
+
+
+def main():
+    from gedepth_amd.mmrt.ddp import init_dist
+    rank, local, world = init_dist('nccl')
+    assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1
+    la, pa = run(True)
+    lb, pb = run(False)
+    # not bit-for-bit: the deformable-attention scatter combines chunks of a value tile with fp32 atomics (run-to-run order)
+    assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(la, lb)), (la, lb)
+    assert (pa - pb).abs().max().item() <= 2e-6, (pa - pb).abs().max().item()
+    dist.destroy_process_group()
+    print('RCCL_DDP_OK', la)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,6 +1,7 @@
 """Parity of every HIP kernel (through the C ABI / autograd wrappers) against the CPU oracle, the
 golden fixtures generated from the reference, and size-independent properties.  Runs on MI355X only."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -383,6 +384,41 @@ def test_ground_embed_adaptive(dev, hw, use_height):
     close(pe.cpu()[ok], pe_ref[ok], atol=1e-4, what='pe_mask')
     close_scaled(lg_.grad, lc.grad, rel=5e-4, what='d logits_lr')
     close_scaled(yg_.grad, yc.grad, rel=1e-4, what='d y_lr')
+
+
+def test_ground_embed_integer_mask_vs_reference(dev, golden):
+    """north_star: "ground-depth integer pixel mask bit-exact".  ge_ground_embed_fwd's uint8 validity mask against the
+    mask read off the reference's own dynamic_pe (tests/golden/make_golden_mask.py) — torch.equal over ALL pixels, no
+    excluded set — for 2x24x40 and 2x88x280, default height and per-sample (DDAD) heights."""
+    from gedepth_amd.kernels import ground_embed_adaptive
+    g = golden('dynamic_pe_mask')
+    for tag in 'ab':
+        pe_raw = T(g[f'{tag}_pe_raw'])
+        B, H, W = pe_raw.shape
+        img = torch.zeros(B, 5, H, W)
+        img[:, 4] = pe_raw
+        img = img.to(dev)
+        lg = T(g[f'{tag}_logits_lr']).to(dev)
+        ones = torch.ones(B, 1, H // 2, W // 2, device=dev)
+        for sfx, h in (('', None), ('_h', T(g[f'{tag}_heights']).to(dev))):
+            pe, _, _, valid = ground_embed_adaptive(lg, ones, img, h, 200.0)
+            ref = T(g[f'{tag}_mask{sfx}'])[:, 0]
+            nd = int((valid.cpu() != ref).sum())
+            assert valid.dtype == torch.uint8 and torch.equal(valid.cpu(), ref), f'{tag}{sfx}: {nd} of {ref.numel()} mask pixels differ'
+            close(pe.cpu(), g[f'{tag}_offset_masked{sfx}'], rtol=1e-5, atol=1e-4, what='offset * mask')
+
+
+def test_ground_embed_integer_mask_full_size_vs_oracle(dev):
+    """The same all-pixel equality at BASELINE.json's 352x1120 (2 images, 788 k pixels) against the CPU oracle, whose
+    mask is itself pinned bit-for-bit to the reference (tests/test_oracle_golden.py)."""
+    from gedepth_amd.kernels import ground_embed_adaptive
+    for seed, height in ((352, None), (7, torch.tensor([1.56, 1.53]))):
+        img, logits, y = _ground_inputs(2, 352, 1120, seed=seed)
+        with torch.no_grad():
+            _, _, _, m_ref = _oracle_adaptive(img, logits, y, height)
+        _, _, _, valid = ground_embed_adaptive(logits.to(dev), y.to(dev), img.to(dev), None if height is None else height.to(dev), 200.0)
+        nd = int((valid.cpu() != m_ref[:, 0].to(torch.uint8)).sum())
+        assert nd == 0, f'{nd} of {valid.numel()} mask pixels differ from the oracle (seed {seed})'
 
 
 def test_ground_embed_golden(dev, golden):
@@ -819,3 +855,39 @@ def test_fused_adamw_matches_torch(dev):
         ours.step()
         for p, q in zip(ref_params, our_params):
             close(q, p, rtol=1e-5, atol=1e-7, what=f'step {step}')
+
+
+def test_ground_plane_and_slope_classes_vs_reference_scripts(dev, golden):
+    """ge_ground_plane / ge_slope_class / ge_slope_class_ddad bit-for-bit against the arrays the reference's own
+    tools/preprocess_data_kitti.py and preprocess_data_ddad.py wrote for a toy calibration tree
+    (tests/golden/make_golden_ground.py): float64 maps, integer class maps, every pixel."""
+    sys_path_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    import importlib.util
+    from gedepth_amd.kernels import ground_plane, slope_class, slope_class_ddad
+    spec = importlib.util.spec_from_file_location('pp_ddad', os.path.join(sys_path_tools, 'preprocess_data_ddad.py'))
+    pp_ddad = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pp_ddad)
+    g = golden('ground_plane')
+    for d in range(2):
+        ref = g[f'kitti{d}_pe']
+        H, W = ref.shape
+        R0, Tr = np.eye(4), g[f'kitti{d}_Tr']
+        R0[:3, :3] = g[f'kitti{d}_R0']
+        A = g[f'kitti{d}_P2'] @ R0 @ Tr                     # host side of tools/preprocess_data_kitti.py (this repo)
+        Rinv = np.linalg.inv(A[:3, :3])
+        RT = Rinv @ A[:3, 3]
+        pe64, pe32 = ground_plane(Rinv[2], float(RT[2] - 1.65), H, W, device=dev)
+        assert np.array_equal(pe64.cpu().numpy(), ref), 'pe float64 map differs from the reference script'
+        assert np.array_equal(pe32.cpu().numpy(), ref.astype(np.float32))
+        for f in range(2):
+            gt = torch.from_numpy(g[f'kitti{d}_gt16_{f}'] / 256).to(dev)
+            k = slope_class(gt, pe32, 1.65, 'round').cpu().numpy()
+            assert np.array_equal(k.astype(np.float64), g[f'kitti{d}_k_{f}']), int((k != g[f'kitti{d}_k_{f}']).sum())
+    for i, cam in enumerate(('CAMERA_01', 'CAMERA_05', 'CAMERA_06', 'CAMERA_09')):
+        ref = g[f'ddad{i}_pe']
+        H, W = ref.shape
+        row2, num = pp_ddad.plane_coefficients(g[f'ddad{i}_K'], g[f'ddad{i}_pose'], g['ddad_lidar_pose'])
+        pe64, _ = ground_plane(row2, num, H, W, device=dev)
+        assert np.array_equal(pe64.cpu().numpy(), ref)
+        k = slope_class_ddad(torch.from_numpy(g[f'ddad{i}_gt']).to(dev), pe64, pp_ddad.CAMERA_HEIGHTS[cam]).cpu().numpy()
+        assert np.array_equal(k.astype(np.int64), g[f'ddad{i}_k']), int((k != g[f'ddad{i}_k']).sum())

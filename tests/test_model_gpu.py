@@ -46,11 +46,29 @@ def dev():
     return torch.device('cuda:0')
 
 
+PARITY_LOG = os.path.join(ROOT, 'gpurun_out', 'parity_e2e.json')
+
+
+def _log_parity(tag, record):
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        data = json.load(open(PARITY_LOG)) if os.path.isfile(PARITY_LOG) else {}
+        data[tag] = record
+        json.dump(data, open(PARITY_LOG, 'w'), indent=1)
+    except OSError:
+        pass
+
+
 @pytest.mark.parametrize('cfg_name,tag,adaptive', [('depthformer_swint_v.py', 'e2e_T_V', False),
                                                    ('depthformer_swint_a.py', 'e2e_T_A', True),
                                                    ('depthformer_a.py', 'e2e_L_A', True)])
 def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
+    """Whole model, fp32, exact-fp32 window attention, against (1) the fixture the reference itself produced on CPU and
+    (2) the same algorithm evaluated in FLOAT64 (tests/f64ref.py), which arbitrates where two correct fp32
+    implementations disagree.  north_star: predicted depth within 1e-4 rel."""
+    import f64ref
     g = golden(tag)
+    f64 = f64ref.run(tag)
     model = build(cfg_name)
     load_filled(model, 'e2e')
     model = model.to(dev)
@@ -59,37 +77,49 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
     metas = [dict(flip=False, ori_shape=(64, 96, 3))] * 2
     model.eval()
     with torch.no_grad():
-        depth = model.encode_decode(img, metas)
-    ref = T(g['depth_eval'])
-    err = ((depth.cpu() - ref).abs() / ref.abs().clamp_min(1e-3)).max().item()
-    assert err < 1e-3, f'eval depth rel err {err:.3e}'      # conv/GEMM library accumulation order differs
+        depth = model.encode_decode(img, metas).cpu().double()
+    ref, ref64 = T(g['depth_eval']).double(), f64['depth_eval']
+    rel = lambda a, b: ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
+    rec = dict(depth_hip_vs_fixture=rel(depth, ref), depth_hip_vs_f64=rel(depth, ref64), depth_fixture_vs_f64=rel(ref, ref64))
+    print(f'\n[{tag}] eval depth max rel err: HIP-fixture {rec["depth_hip_vs_fixture"]:.2e}  HIP-f64 {rec["depth_hip_vs_f64"]:.2e}  '
+          f'fixture-f64 {rec["depth_fixture_vs_f64"]:.2e}')
+    # north star bound, against the float64 truth; against the fp32 fixture the fixture's own rounding error adds
+    assert rec['depth_hip_vs_f64'] <= 1e-4, rec
+    assert rec['depth_hip_vs_fixture'] <= 1e-4 + rec['depth_fixture_vs_f64'], rec
     model.train()
     kw = dict(pe_k_gt=kgt) if adaptive else {}
     out = model.train_step(dict(img=img, img_metas=metas, depth_gt=gt, **kw), None)
     names = json.loads(str(g['loss_names']))
     for n, v in zip(names, g['loss_values']):
         assert abs(out['log_vars'][n] - v) <= 1e-5 * abs(v) + 1e-6, (n, out['log_vars'][n], v)
+        assert abs(out['log_vars'][n] - f64['log_vars'][n]) <= 1e-5 * abs(v) + 1e-6, (n, out['log_vars'][n], f64['log_vars'][n])
     out['loss'].backward()
     params = dict(model.named_parameters())
     assert all(p.grad is not None for p in params.values())
-    for k in g.files:
-        if k.startswith('grad::'):
-            gr = params[k[6:]].grad.flatten()
-            gr = gr[::max(1, gr.numel() // 50000)].cpu()
-            refg = T(g[k])
-            l2rel = ((gr - refg).norm() / (refg.norm() + 1e-30)).item()
-            # Swin-T: <= 5e-5 everywhere except four stage-0 tensors at ~4e-4 since LayerNorm runs as the HIP kernel (2.5e-5
-            # with ATen's): qkv.bias / relative_position_bias_table of blocks 0-1 — directions the softmax is invariant to,
-            # whose gradients are sums that cancel to rounding level — and the patch-embed weight behind them.  The kernel is
-            # closer to float64 than ATen's on every LayerNorm of this model (7e-8 vs 8e-8 rel. l2, forward and backward,
-            # scratch/dbg_ln3.py); the fixture comes from CPU kernels that round like ATen's.
-            # Swin-L (24 blocks, fill-rule weights): ~6e-3 on the backbone gradients although the losses agree to 1e-7 and
-            # every conv / linear / norm layer's own backward agrees to 1e-6 with a float64 CPU recomputation (scratch
-            # probes, DESIGN.md "open items") — the same sensitivity; bounded here, tracked there.
-            tol = 1e-3 if 'T' in tag else 1.5e-2
-            assert l2rel <= tol, (k, l2rel)
+    # gradients: every parameter against float64; the fixture's (reference fp32 CPU) own distance to float64 is the
+    # yardstick — the HIP path must be within 1e-4 l2rel of the truth, or no further from it than 2x the reference is
+    table, worst = [], 0.0
+    for k, p in params.items():
+        e_hip = f64ref.l2rel(f64ref.sample(p.grad), f64ref.sample(f64['grads'][k]))
+        fk = 'grad::' + k
+        e_ref = f64ref.l2rel(T(g[fk]), f64ref.sample(f64['grads'][k])) if fk in g.files else None
+        table.append((k, e_hip, e_ref))
+        worst = max(worst, e_hip)
+    table.sort(key=lambda r: -r[1])
+    print(f'[{tag}] gradient l2rel vs float64 (worst 12 of {len(table)}):')
+    for k, e_hip, e_ref in table[:12]:
+        print(f'   {k:72s} HIP {e_hip:.2e}' + (f'   reference-fixture {e_ref:.2e}' if e_ref is not None else ''))
+    rec['grad_worst_hip_vs_f64'] = worst
+    rec['grad_table'] = [(k, e, r) for k, e, r in table[:40]]
+    rec['grad_fixture_vs_f64'] = {k: r for k, e, r in table if r is not None}
+    _log_parity(tag, rec)
+    ref_worst = max(r for _, _, r in table if r is not None)
+    for k, e_hip, e_ref in table:
+        bound = max(1e-4, 2.0 * (e_ref if e_ref is not None else ref_worst))
+        assert e_hip <= bound, (k, e_hip, e_ref, bound)
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())).item()
-    assert abs(total - float(g['grad_norm_total'])) <= (2e-4 if 'T' in tag else 5e-3) * float(g['grad_norm_total'])
+    total64 = torch.sqrt(sum((v.double() ** 2).sum() for v in f64['grads'].values())).item()
+    assert abs(total - total64) <= 1e-4 * total64, (total, total64)
 
 
 def test_full_size_forward_vs_oracle(dev):
@@ -107,8 +137,12 @@ def test_full_size_forward_vs_oracle(dev):
         out = model.encode_decode(batch['img'].to(dev), batch['img_metas'])
     assert out.shape == (1, 1, 352, 1120)
     rel = ((out.cpu() - ref).abs() / ref.abs().clamp_min(1e-3))
-    assert rel.max().item() < 2e-3, rel.max().item()
-    assert rel.mean().item() < 1e-4, rel.mean().item()
+    print(f'\n[full size 1x352x1120 Swin-T-V] eval depth rel err vs fp32 oracle: max {rel.max().item():.2e} mean {rel.mean().item():.2e}')
+    _log_parity('full_size_T_V', dict(depth_max_rel=rel.max().item(), depth_mean_rel=rel.mean().item()))
+    # two fp32 evaluations (CPU oracle / HIP) of the same 12-block network: each is ~4e-5 from float64 at 64x96
+    # (test_e2e_vs_reference_fixture), so their mutual distance is bounded by 2e-4; the mean stays 20x below 1e-4
+    assert rel.max().item() <= 2e-4, rel.max().item()
+    assert rel.mean().item() <= 5e-6, rel.mean().item()
 
 
 def test_bf16_autocast_train_step(dev):
@@ -131,3 +165,127 @@ def test_bf16_autocast_train_step(dev):
     for k, v in ref['log_vars'].items():
         assert abs(out['log_vars'][k] - v) <= 5e-2 * abs(v) + 1e-3, (k, out['log_vars'][k], v)
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+# ------------------------------------------------------------------ BASELINE.json configs on the HIP path
+def _grad_vector(model):
+    return torch.cat([p.grad.detach().flatten().float() for p in model.parameters()])
+
+
+def test_config2_bf16_full_shape_step_vs_fp32(dev):
+    """configs[1] at its real shape — DepthFormer-SwinT + GEDepth-Vanilla, 8x352x1120, bf16 autocast, full step — against
+    the fp32 step of the same model on the same batch: loss within the bf16 bound, gradient direction preserved."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    torch.manual_seed(0)
+    model = build('depthformer_swint_v.py')
+    model.init_weights()
+    model = model.to(dev).train()
+    batch = synthetic_batch(8, 352, 1120, seed=1234, device=dev)
+    ref = model.train_step(batch, None)                     # fp32 storage + arithmetic (exact-fp32 window attention)
+    ref['loss'].backward()
+    g32 = _grad_vector(model)
+    for p in model.parameters():
+        p.grad = None
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    optimizer.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model.train_step(batch, optimizer)
+    out['loss'].backward()
+    g16 = _grad_vector(model)
+    l32, l16 = ref['log_vars']['loss'], out['log_vars']['loss']
+    cos = torch.nn.functional.cosine_similarity(g16.double(), g32.double(), dim=0).item()
+    nrm = (g16.norm() / g32.norm()).item()
+    print(f'\n[config #2 8x352x1120] loss fp32 {l32:.6f} bf16 {l16:.6f} rel {abs(l16 - l32) / abs(l32):.2e}; '
+          f'grad cosine {cos:.5f}, |g_bf16|/|g_fp32| {nrm:.4f}')
+    _log_parity('config2_bf16_vs_fp32', dict(loss_fp32=l32, loss_bf16=l16, grad_cosine=cos, grad_norm_ratio=nrm))
+    assert abs(l16 - l32) <= 1e-2 * abs(l32), (l16, l32)        # bf16 has 8 mantissa bits: 4e-3 per rounding
+    assert torch.isfinite(g16).all() and cos >= 0.98 and 0.9 <= nrm <= 1.1, (cos, nrm)
+    optimizer.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_config4_ddad_native_resolution_train_step(dev):
+    """configs[3]: DepthFormer-SwinL + GEDepth-Adaptive at the native DDAD resolution 1x5x1216x1936 (per-camera height
+    kwarg, loading.py:923-932): one full bf16 training step on the HIP path — finite losses, every parameter gets a finite
+    gradient, and the deformable-attention backward runs the binned path with ONE HEAD PER WORKGROUP histograms (the
+    6e3 value tiles x 8 heads of this map do not fit one LDS histogram)."""
+    import ctypes
+    from gedepth_amd import hip
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    H, W = 1216, 1936
+    shapes = [(H // 4 // 2 ** i, W // 4 // 2 ** i) for i in range(4)]
+    arr = (ctypes.c_int * 8)(*[v for hw in shapes for v in hw])
+    out4 = (ctypes.c_int * 4)()
+    nv = sum(h * w for h, w in shapes)
+    hip.check(hip.lib().ge_msda_bwd_plan(ctypes.cast(arr, ctypes.c_void_p), 1, nv, (H // 2) * (W // 2), 8, 4, 8,
+                                         ctypes.cast(out4, ctypes.c_void_p)), 'ge_msda_bwd_plan')
+    assert out4[0] == 1 and out4[1] == 8, list(out4)            # binned, per-head histograms
+    kitti4 = (ctypes.c_int * 4)()
+    ks = [(88, 280), (44, 140), (22, 70), (11, 35)]
+    hip.check(hip.lib().ge_msda_bwd_plan(ctypes.cast((ctypes.c_int * 8)(*[v for hw in ks for v in hw]), ctypes.c_void_p), 8, 32725,
+                                         98560, 8, 4, 8, ctypes.cast(kitti4, ctypes.c_void_p)), 'ge_msda_bwd_plan')
+    assert kitti4[0] == 1 and kitti4[1] == 1, list(kitti4)      # KITTI shape: all heads in one histogram
+    torch.manual_seed(0)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_a_ddad.py'))
+    cfg.model.pretrained = None
+    from gedepth_amd.depth.models import build_depther
+    model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    model.init_weights()
+    model = model.to(dev).train()
+    optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    batch = synthetic_batch(1, H, W, seed=4, device=dev)
+    batch['height'] = torch.tensor([1.56], device=dev)
+    optimizer.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model.train_step(batch, optimizer)
+    out['loss'].backward()
+    lv = out['log_vars']
+    assert set(lv) >= {'decode.loss_depth', 'decode.loss_dynamic_pe', 'loss'} and all(np.isfinite(v) for v in lv.values()), dict(lv)
+    missing = [k for k, p in model.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    assert model.last_valid_mask.shape == (1, H, W) and model.last_valid_mask.dtype == torch.uint8
+    optimizer.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    print(f'\n[config #4 1x1216x1936 Swin-L-A bf16] losses {dict((k, round(v, 5)) for k, v in lv.items())}')
+
+
+def test_ddad_per_camera_height_vs_oracle(dev):
+    """The DDAD branch of dynamic_pe (encoder_decoder.py:88-94: per-sample camera height) through the whole fp32 model
+    against the CPU oracle on the same seeded input/weights (2x5x64x96, Swin-L-A)."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    model = build('depthformer_a_ddad.py')
+    sd = load_filled(model, 'ddad')
+    P = {k: v.clone() for k, v in sd.items()}
+    model = model.to(dev).train()
+    set_exact(model)
+    batch = synthetic_batch(2, 64, 96, seed=11, valid_fraction=0.3)
+    heights = torch.tensor([1.56, 1.53])
+    losses, _ = O.forward_train(batch['img'], batch['depth_gt'], batch['pe_k_gt'], P, dict(O.SWIN_L, adaptive=True), train_bn=True,
+                                height=heights)
+    _, ref = O.parse_losses(losses)
+    gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out = model.train_step(dict(gb, height=heights.to(dev)), None)
+    for k, v in ref.items():
+        assert abs(out['log_vars'][k] - v) <= 1e-5 * abs(v) + 1e-6, (k, out['log_vars'][k], v)
+    out0 = model.train_step(gb, None)                       # default 1.65 m must give a different ground embedding
+    assert abs(out0['log_vars']['loss'] - out['log_vars']['loss']) > 1e-6
+
+
+def test_rccl_gradient_exchange_single_rank(dev):
+    """The N-GPU path on one GPU: FlatDDP with the nccl (= RCCL) backend forced on a single rank (GE_DDP_FORCE=1) — bucketed
+    async all-reduce from the post-accumulate hooks, fused scalar reduce — must reproduce the plain step (to fp32 atomics' run-to-run order)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GE_DDP_FORCE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_rccl_worker.py')], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'RCCL_DDP_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
