@@ -29,12 +29,28 @@ def collate(samples):
     return out
 
 
+def worker_init_fn(worker_id, num_workers, rank, seed):
+    """depth/datasets/builder.py:152-157: every worker of every rank gets its own stream — the transforms draw from
+    ``np.random`` (Resize ratio, RandomRotate, RandomFlip, RandomCrop, ColorAug), which torch does not re-seed in forked
+    workers.  seed=None: derive from the worker's torch seed (distinct per worker and epoch-stable)."""
+    import random
+
+    import numpy as np
+    worker_seed = (num_workers * rank + worker_id + seed) if seed is not None else (torch.initial_seed() + rank) % 2 ** 32
+    np.random.seed(worker_seed % 2 ** 32)
+    random.seed(worker_seed)
+    torch.manual_seed(worker_seed)
+
+
 def build_dataloader(dataset, samples_per_gpu, workers_per_gpu=0, dist=True, shuffle=True, seed=None, drop_last=False,
                      pin_memory=True, **kwargs):
+    from functools import partial
     rank, world = get_dist_info()
     sampler = DistributedSampler(dataset, world, rank, shuffle=shuffle, seed=seed or 0) if dist else None
+    init_fn = partial(worker_init_fn, num_workers=workers_per_gpu, rank=rank, seed=seed)
     return DataLoader(dataset, batch_size=samples_per_gpu, sampler=sampler, shuffle=(shuffle and sampler is None),
                       num_workers=workers_per_gpu, collate_fn=collate, pin_memory=pin_memory, drop_last=drop_last,
+                      worker_init_fn=init_fn,
                       persistent_workers=workers_per_gpu > 0)      # the iter-based runner re-enters the loader every epoch
 
 

@@ -120,15 +120,68 @@ class FusedAdamW(torch.optim.Optimizer):
                                     hip.stream()), 'ge_adamw_step')
 
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
-                    param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
+        """``torch.optim.AdamW`` layout (what mmcv's CheckpointHook stores and the reference's checkpoints hold):
+        ``state[i] = {step, exp_avg, exp_avg_sq}`` per parameter — views sliced out of the arenas — and ``param_groups``
+        with parameter ids, ids running over the groups in order."""
+        index = {id(p): i for i, p in enumerate(p for g in self.param_groups for p in g['params'])}
+        state = {}
+        for p, (off, n) in zip(self.arena.params, self.arena.slices()):
+            state[index[id(p)]] = dict(step=torch.tensor(float(self.step_count)),
+                                       exp_avg=self.exp_avg[off:off + n].view_as(p).clone(),
+                                       exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p).clone())
+        groups = []
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d['params'] = [index[id(p)] for p in g['params']]
+            groups.append(d)
+        return dict(state=state, param_groups=groups)
 
-    def load_state_dict(self, state):
-        self.step_count = int(state['step'])
-        self.exp_avg.copy_(state['exp_avg'])
-        self.exp_avg_sq.copy_(state['exp_avg_sq'])
-        for g, s in zip(self.param_groups, state['param_groups']):
-            g.update(s)
+    def load_state_dict(self, state_dict):
+        """Accepts the torch layout above (ours, mmcv's, the reference's) and the flat-arena layout of round 1
+        (``{step, exp_avg, exp_avg_sq, param_groups}``).  Shapes are validated per parameter before anything is copied."""
+        if 'state' not in state_dict:                                   # round-1 flat layout
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if tuple(state_dict[k].shape) != (self.arena.numel,):
+                    raise ValueError(f'optimizer {k}: arena of {tuple(state_dict[k].shape)} elements, this model needs {self.arena.numel}')
+            self.step_count = int(state_dict['step'])
+            self.exp_avg.copy_(state_dict['exp_avg'].to(self.exp_avg.device, torch.float32))
+            self.exp_avg_sq.copy_(state_dict['exp_avg_sq'].to(self.exp_avg.device, torch.float32))
+            for g, s in zip(self.param_groups, state_dict['param_groups']):
+                g.update({k: v for k, v in s.items() if k != 'params'})
+            return
+        saved_groups = state_dict['param_groups']
+        if len(saved_groups) != len(self.param_groups):
+            raise ValueError(f'optimizer state has {len(saved_groups)} parameter groups, this optimizer {len(self.param_groups)}')
+        own_ids, id_of = [], {}
+        for g, sg in zip(self.param_groups, saved_groups):
+            if len(g['params']) != len(sg['params']):
+                raise ValueError('optimizer state: a parameter group has a different number of parameters')
+            for p, pid in zip(g['params'], sg['params']):
+                id_of[id(p)] = pid
+        st = state_dict['state']
+        st = {int(k): v for k, v in st.items()}
+        plan, steps = [], set()
+        for p, (off, n) in zip(self.arena.params, self.arena.slices()):
+            rec = st.get(id_of[id(p)])
+            if rec is None:                                              # parameter that never received a gradient
+                plan.append((off, n, None))
+                continue
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if tuple(rec[k].shape) != tuple(p.shape):
+                    raise ValueError(f'optimizer state {k} of parameter {id_of[id(p)]}: shape {tuple(rec[k].shape)} != {tuple(p.shape)}')
+            steps.add(int(float(rec['step'])))
+            plan.append((off, n, rec))
+        if len(steps) > 1:
+            raise NotImplementedError(f'FusedAdamW keeps one step counter; the checkpoint has {sorted(steps)}')
+        for off, n, rec in plan:
+            for buf, k in ((self.exp_avg, 'exp_avg'), (self.exp_avg_sq, 'exp_avg_sq')):
+                if rec is None:
+                    buf[off:off + n].zero_()
+                else:
+                    buf[off:off + n].copy_(rec[k].reshape(-1).to(buf.device, torch.float32))
+        self.step_count = steps.pop() if steps else 0
+        for g, s in zip(self.param_groups, saved_groups):
+            g.update({k: v for k, v in s.items() if k != 'params'})
 
 
 def paramwise_groups(model, base_lr, base_wd, paramwise_cfg=None):

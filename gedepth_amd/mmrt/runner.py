@@ -163,6 +163,7 @@ class IterBasedRunner:
         self.model, self.optimizer, self.work_dir, self.logger, self.meta = model, optimizer, work_dir, logger, meta or {}
         self.max_iters = max_iters
         self.iter = 0
+        self.epoch = 0
         self.hooks = []
         self.outputs = None
         self.current_lr = optimizer.defaults['lr']
@@ -194,6 +195,15 @@ class IterBasedRunner:
         for h in self.hooks:
             getattr(h, name)(self)
 
+    @staticmethod
+    def _set_epoch(loader, epoch):
+        sampler = getattr(loader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)
+        batch_sampler = getattr(loader, 'batch_sampler', None)
+        if hasattr(getattr(batch_sampler, 'sampler', None), 'set_epoch') and batch_sampler.sampler is not sampler:
+            batch_sampler.sampler.set_epoch(epoch)
+
     def _to_device(self, batch, device):
         return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
@@ -203,11 +213,19 @@ class IterBasedRunner:
         device = next(self.model.parameters()).device
         self.model.train()
         self.call_hook('before_run')
+        # mmcv IterLoader semantics: an epoch counter that re-seeds the DistributedSampler on every restart of the loader
+        # (without set_epoch every epoch replays the same permutation and per-rank shard); on resume it is derived from
+        # the iteration count
+        per_epoch = max(1, len(loader)) if hasattr(loader, '__len__') else 1
+        self.epoch = self.iter // per_epoch
+        self._set_epoch(loader, self.epoch)
         it = iter(loader)
         while self.iter < self.max_iters:
             try:
                 batch = next(it)
             except StopIteration:
+                self.epoch += 1
+                self._set_epoch(loader, self.epoch)
                 it = iter(loader)
                 batch = next(it)
             batch = self._to_device(batch, device)
@@ -230,7 +248,7 @@ class IterBasedRunner:
 
     def load_checkpoint(self, path, map_location='cpu', strict=False):
         model = self.model.module if hasattr(self.model, 'module') else self.model
-        return load_checkpoint(model, path, map_location, strict)
+        return load_checkpoint(model, path, map_location, strict, logger=self.logger)
 
     def resume(self, path, map_location='cpu'):
         ckpt = self.load_checkpoint(path, map_location)

@@ -42,7 +42,6 @@ def use_miopen_find_db(path=MIOPEN_DB):
     workloads from the db (+6 % step rate) instead of timing all solvers for ~5 minutes on a fresh machine.  The db is
     copied to a scratch directory because MIOpen appends to it while running."""
     import shutil
-    import tempfile
     if os.environ.get('MIOPEN_USER_DB_PATH'):
         return True                                    # the user manages the db
     files = [f for f in (os.listdir(path) if os.path.isdir(path) else []) if f.endswith('db.txt')]
@@ -53,12 +52,25 @@ def use_miopen_find_db(path=MIOPEN_DB):
     for f in sorted(files):
         with open(os.path.join(path, f), 'rb') as fh:
             digest.update(fh.read())
-    # one scratch copy per committed content, user and rank: an updated db never hides behind a stale copy
-    dst = os.path.join(tempfile.gettempdir(), f'gedepth_amd_miopen_db_{digest.hexdigest()[:10]}_{os.getuid()}_'
-                                              f'{os.environ.get("LOCAL_RANK", "0")}')
-    os.makedirs(dst, exist_ok=True)
+    # one private copy per committed content and rank under a user-owned 0700 cache directory (never the shared tempdir:
+    # a predictable path there could be pre-created by another local user and MIOpen reads AND appends to it); symlinks are
+    # refused and the copied files are always rewritten
+    cache = os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache')
+    base = os.path.join(cache, 'gedepth_amd')
+    dst = os.path.join(base, f'miopen_db_{digest.hexdigest()[:10]}_{os.environ.get("LOCAL_RANK", "0")}')
+    for d in (base, dst):
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.lstat(d)
+        import stat
+        if stat.S_ISLNK(st.st_mode) or st.st_uid != os.getuid():
+            raise RuntimeError(f'{d} is a symlink or owned by another user; refusing to use it as the MIOpen user db')
+        os.chmod(d, 0o700)
     for f in files:
-        if not os.path.isfile(os.path.join(dst, f)):
-            shutil.copy(os.path.join(path, f), os.path.join(dst, f))
+        target = os.path.join(dst, f)
+        if os.path.islink(target):
+            os.unlink(target)
+        tmp = target + f'.{os.getpid()}.tmp'
+        shutil.copyfile(os.path.join(path, f), tmp)
+        os.replace(tmp, target)
     os.environ['MIOPEN_USER_DB_PATH'] = dst
     return True

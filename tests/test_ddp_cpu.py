@@ -186,6 +186,92 @@ def test_runner_hooks_checkpoint_resume(tmp_path):
         assert torch.equal(v, model2.state_dict()[k])
 
 
+def test_runner_reseeds_sampler_each_epoch_and_on_resume():
+    """mmcv IterLoader semantics: ``sampler.set_epoch`` on every restart of the loader (a DistributedSampler otherwise
+    replays one permutation for ever), epoch counter derived from the iteration on resume."""
+    from torch.utils.data import DataLoader, DistributedSampler
+    from gedepth_amd.mmrt.runner import IterBasedRunner
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return dict(x=torch.full((8,), float(i)), y=torch.zeros(1), idx=torch.tensor(i))
+
+    class Spy(Toy):
+        seen = []
+
+        def train_step(self, batch, optimizer, **kw):
+            Spy.seen.append(batch['idx'].tolist())
+            return super().train_step(batch, optimizer, **kw)
+    torch.manual_seed(0)
+    model = Spy()
+    sampler = DistributedSampler(DS(), num_replicas=1, rank=0, shuffle=True, seed=3)
+    calls = []
+    orig = sampler.set_epoch
+    sampler.set_epoch = lambda e: (calls.append(e), orig(e))[1]
+    loader = DataLoader(DS(), batch_size=3, sampler=sampler)
+    runner = IterBasedRunner(model, ArenaSGD(model), logger=lambda m: None, max_iters=6)
+    runner.register_training_hooks(dict(policy='CosineAnnealing', min_lr_ratio=1e-3, by_epoch=False), dict(grad_clip=None))
+    Spy.seen = []
+    runner.run([loader])
+    assert calls == [0, 1, 2] and runner.epoch == 2
+    epochs = [sum(Spy.seen[2 * e:2 * e + 2], []) for e in range(3)]
+    assert all(sorted(e) == list(range(6)) for e in epochs) and len({tuple(e) for e in epochs}) > 1, epochs
+    calls.clear()
+    r2 = IterBasedRunner(model, ArenaSGD(model), logger=lambda m: None, max_iters=6)
+    r2.register_training_hooks(dict(policy='CosineAnnealing', min_lr_ratio=1e-3, by_epoch=False), dict(grad_clip=None))
+    r2.iter = 4                                               # as after resume(): 4 iterations = 2 epochs of 2 batches
+    r2.run([loader])
+    assert calls[0] == 2
+
+
+def test_loader_workers_get_distinct_reproducible_seeds():
+    """depth/datasets/builder.py:152-157: seed = num_workers * rank + worker_id + seed for numpy / random / torch."""
+    import numpy as np
+    from gedepth_amd.depth.datasets.loader import build_dataloader
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 8
+
+        def __getitem__(self, i):
+            info = torch.utils.data.get_worker_info()
+            return dict(worker=torch.tensor(info.id), draw=torch.tensor(np.random.randint(0, 2 ** 31 - 1)))
+
+    def draws(seed):
+        out = {}
+        for b in build_dataloader(DS(), 1, workers_per_gpu=2, dist=False, shuffle=False, seed=seed, pin_memory=False):
+            out.setdefault(int(b['worker']), []).append(int(b['draw']))
+        return out
+    a, b = draws(5), draws(5)
+    assert a == b and a[0] != a[1], (a, b)                     # reproducible, and the two workers differ
+    exp = np.random.RandomState(2 * 0 + 0 + 5).randint(0, 2 ** 31 - 1)
+    assert a[0][0] == exp
+    c = draws(None)
+    assert c[0] != c[1]
+
+
+def test_load_checkpoint_reports_and_refuses_mismatches(tmp_path):
+    from gedepth_amd.mmrt.checkpoint import load_checkpoint, save_checkpoint
+    m = Toy()
+    save_checkpoint(m, str(tmp_path / 'a.pth'))
+    logs = []
+    load_checkpoint(Toy(), str(tmp_path / 'a.pth'), logger=logs.append)
+    assert not logs
+    sd = m.state_dict()
+    torch.save(dict(state_dict={'backbone.' + k: v for k, v in sd.items()}), tmp_path / 'prefixed.pth')
+    with pytest.raises(RuntimeError, match='none of the'):
+        load_checkpoint(Toy(), str(tmp_path / 'prefixed.pth'))
+    first = next(iter(sd))
+    part = {k: v for k, v in sd.items() if k != first}
+    part['stray.weight'] = torch.zeros(1)
+    torch.save(dict(state_dict=part), tmp_path / 'part.pth')
+    load_checkpoint(Toy(), str(tmp_path / 'part.pth'), logger=logs.append)
+    assert any('missing' in l and first in l for l in logs) and any('unexpected' in l and 'stray.weight' in l for l in logs)
+
+
 # ---------------------------------------------------------------- distributed evaluation (SURVEY.md §8 f1, depth/apis/test.py)
 class _IndexDataset(torch.utils.data.Dataset):
     """5 samples (odd on purpose: the DistributedSampler pads rank 1 with a repeated index)."""

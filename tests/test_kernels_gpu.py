@@ -857,6 +857,64 @@ def test_fused_adamw_matches_torch(dev):
             close(q, p, rtol=1e-5, atol=1e-7, what=f'step {step}')
 
 
+def test_fused_adamw_state_dict_is_torch_layout(dev):
+    """Checkpoint interop (mmcv layout: 'optimizer' = a torch.optim state dict): a torch.optim.AdamW state loads into
+    FusedAdamW and vice versa, and training continues identically; mismatching shapes are refused before any copy."""
+    from gedepth_amd.mmrt.optim import FusedAdamW
+    torch.manual_seed(1)
+    shapes = [(17, 5), (40,), (3, 2, 3, 3)]
+    mk = lambda: [torch.randn(s, device=dev, generator=torch.Generator(dev).manual_seed(7 + i)).requires_grad_(True)
+                  for i, s in enumerate(shapes)]
+    groups = lambda ps: [dict(params=[ps[0]], weight_decay=0.01), dict(params=[ps[1]], weight_decay=0.0),
+                         dict(params=[ps[2]], weight_decay=0.01)]
+    tp, fp = mk(), mk()
+    ref = torch.optim.AdamW(groups(tp), lr=2e-3)
+    ours = FusedAdamW(groups(fp), lr=2e-3)
+
+    def both(n):
+        for _ in range(n):
+            grads = [torch.randn(s, device=dev) for s in shapes]
+            for p, q, g in zip(tp, fp, grads):
+                p.grad = g.clone()
+                q.grad.copy_(g)
+            ref.step()
+            ours.step()
+    both(2)
+    sd = ours.state_dict()
+    assert set(sd) == {'state', 'param_groups'} and set(sd['state']) == {0, 1, 2}
+    assert [g['params'] for g in sd['param_groups']] == [[0], [1], [2]]
+    assert tuple(sd['state'][2]['exp_avg'].shape) == shapes[2] and float(sd['state'][0]['step']) == 2.0
+    for i in range(3):
+        close(sd['state'][i]['exp_avg_sq'], ref.state_dict()['state'][i]['exp_avg_sq'], rtol=1e-5, atol=1e-9, what='exp_avg_sq')
+    # torch -> fused: a fresh FusedAdamW resumes from the torch optimizer's checkpoint
+    fp2 = [p.detach().clone().requires_grad_(True) for p in tp]
+    ours2 = FusedAdamW(groups(fp2), lr=2e-3)
+    ours2.load_state_dict(ref.state_dict())
+    # fused -> torch
+    tp2 = [p.detach().clone().requires_grad_(True) for p in fp]
+    ref2 = torch.optim.AdamW(groups(tp2), lr=2e-3)
+    ref2.load_state_dict(sd)
+    grads = [torch.randn(s, device=dev) for s in shapes]
+    for plist, opt in ((tp, ref), (fp2, ours2), (tp2, ref2)):
+        for p, g in zip(plist, grads):
+            if opt is ours2:
+                p.grad.copy_(g)
+            else:
+                p.grad = g.clone()
+        opt.step()
+    for a, b, c in zip(tp, fp2, tp2):
+        close(b, a, rtol=1e-5, atol=1e-7, what='torch state -> FusedAdamW')
+        close(c, a, rtol=1e-5, atol=1e-7, what='FusedAdamW state -> torch')
+    bad = ref.state_dict()
+    bad['state'][1]['exp_avg'] = torch.zeros(41)
+    before = ours2.exp_avg.clone()
+    with pytest.raises(ValueError):
+        ours2.load_state_dict(bad)
+    assert torch.equal(before, ours2.exp_avg)                      # nothing was copied
+    with pytest.raises(ValueError):
+        ours2.load_state_dict(dict(step=1, exp_avg=torch.zeros(5), exp_avg_sq=torch.zeros(5), param_groups=[]))
+
+
 def test_ground_plane_and_slope_classes_vs_reference_scripts(dev, golden):
     """ge_ground_plane / ge_slope_class / ge_slope_class_ddad bit-for-bit against the arrays the reference's own
     tools/preprocess_data_kitti.py and preprocess_data_ddad.py wrote for a toy calibration tree
