@@ -1,0 +1,93 @@
+// Shared definitions of the deformable-attention kernels (msda.hip: streaming / binned kernels, msda_win.hip: the
+// LDS-window kernels).
+#pragma once
+#include "common.h"
+
+#define MSDA_MAX_L 8
+struct MsdaLevels { int H[MSDA_MAX_L]; int W[MSDA_MAX_L]; int start[MSDA_MAX_L]; };
+
+
+// CPL channels per lane: 16-byte accesses for both storage types (fp32: 4 channels, bf16: 8 channels)
+template <typename T> struct Lanes;
+template <> struct Lanes<float> { static constexpr int CPL = 4; };
+template <> struct Lanes<bf16_t> { static constexpr int CPL = 8; };
+template <typename T> struct VecL;
+template <> struct VecL<float> {
+  static __device__ __forceinline__ void ld(const float* p, float v[4]) { V8<float>::ld(p, v); }
+  static __device__ __forceinline__ void st(float* p, const float v[4]) { V8<float>::st(p, v); }
+};
+template <> struct VecL<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
+    const uint4 t = *(const uint4*)p;
+    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
+    uint4 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+    *(uint4*)p = t;
+  }
+};
+
+
+// Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MB L2.  The sampling kernels read a sliding
+// neighbourhood of `value`, so neighbouring queries should meet in the SAME L2: XCD x works on the x-th contiguous eighth of
+// the (batch, query) range (one image per XCD at 8 images) instead of every eighth workgroup of all of it.
+// rocprofv3 FETCH_SIZE, forward kernel, 8x352x1120: 10.0 GB per launch with the plain mapping.
+#define MSDA_XCDS 8
+__device__ __forceinline__ long msda_xcd_block(unsigned bid, unsigned nblk) {      // nblk is a multiple of MSDA_XCDS
+  return (long)(bid % MSDA_XCDS) * (nblk / MSDA_XCDS) + bid / MSDA_XCDS;
+}
+static inline unsigned msda_grid(long n_items, int per_block) {
+  long b = (n_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  b = (b + MSDA_XCDS - 1) / MSDA_XCDS * MSDA_XCDS;
+  return (unsigned)b;
+}
+
+
+// <gradient row piece, value row piece> over the 16 bytes a lane holds: 4 fp32 FMAs, or 4 x v_dot2c_f32_bf16 on the raw
+// bf16 pairs (no bf16 -> f32 unpacking: 16 instead of 64 VALU per sampling point for the four corners)
+typedef unsigned int lw_raw_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <typename T> struct RowDot;
+template <> struct RowDot<float> {
+  static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += __uint_as_float(a[i]) * __uint_as_float(b[i]);
+    return s;
+  }
+};
+template <> struct RowDot<bf16_t> {
+  static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]), __builtin_bit_cast(bf16x2_t, b[i]), s, false);
+    return s;
+  }
+};
+
+
+static inline int msda_levels(const int* spatial_hw, int L, int Nv, MsdaLevels& lv) {
+  if (L < 1 || L > MSDA_MAX_L) return GE_ERR_UNSUPPORTED;
+  long start = 0;
+  for (int l = 0; l < L; ++l) {
+    lv.H[l] = spatial_hw[2 * l]; lv.W[l] = spatial_hw[2 * l + 1]; lv.start[l] = (int)start;
+    if (lv.H[l] <= 0 || lv.W[l] <= 0) return GE_ERR_BAD_ARG;
+    start += (long)lv.H[l] * lv.W[l];
+  }
+  return start == Nv ? GE_OK : GE_ERR_BAD_ARG;
+}
+
+
+// LDS-window kernels (msda_win.hip); query geometry = n_qseg (H, W) segments of queries in raster order
+int msda_win_supported(int B, int Nq, int nH, int L, int P, int Nv);
+int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc, const float* attw,
+                        void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, hipStream_t s);
+int msda_bwd_lw_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc,
+                           const float* attw, const void* gout, float* d_loc, float* d_attw, int B, int Nv, int Nq, int nH, int L,
+                           int P, int dtype, hipStream_t s);

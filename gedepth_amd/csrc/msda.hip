@@ -10,12 +10,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include "common.h"
+#include "msda.h"
 #include <string.h>
 #include <mutex>
 #include <vector>
-
-#define MSDA_MAX_L 8
-struct MsdaLevels { int H[MSDA_MAX_L]; int W[MSDA_MAX_L]; int start[MSDA_MAX_L]; };
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
@@ -38,51 +36,12 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
-// CPL channels per lane: 16-byte accesses for both storage types (fp32: 4 channels, bf16: 8 channels)
-template <typename T> struct Lanes;
-template <> struct Lanes<float> { static constexpr int CPL = 4; };
-template <> struct Lanes<bf16_t> { static constexpr int CPL = 8; };
-template <typename T> struct VecL;
-template <> struct VecL<float> {
-  static __device__ __forceinline__ void ld(const float* p, float v[4]) { Vec4<float>::ld(p, v); }
-  static __device__ __forceinline__ void st(float* p, const float v[4]) { Vec4<float>::st(p, v); }
-};
-template <> struct VecL<bf16_t> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float v[8]) {
-    const uint4 t = *(const uint4*)p;
-    const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float v[8]) {
-    uint4 t;
-    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16); t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    t.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16); t.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
-    *(uint4*)p = t;
-  }
-};
-
 __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 8, 64);
   v += __shfl_xor(v, 4, 64);
   v += __shfl_xor(v, 2, 64);
   v += __shfl_xor(v, 1, 64);
   return v;
-}
-
-// Workgroups are dealt round-robin to the 8 XCDs, each with a private 4 MB L2.  The sampling kernels read a sliding
-// neighbourhood of `value`, so neighbouring queries should meet in the SAME L2: XCD x works on the x-th contiguous eighth of
-// the (batch, query) range (one image per XCD at 8 images) instead of every eighth workgroup of all of it.
-// rocprofv3 FETCH_SIZE, forward kernel, 8x352x1120: 10.0 GB per launch with the plain mapping.
-#define MSDA_XCDS 8
-__device__ __forceinline__ long msda_xcd_block(unsigned bid, unsigned nblk) {      // nblk is a multiple of MSDA_XCDS
-  return (long)(bid % MSDA_XCDS) * (nblk / MSDA_XCDS) + bid / MSDA_XCDS;
-}
-static inline unsigned msda_grid(long n_items, int per_block) {
-  long b = (n_items + per_block - 1) / per_block;
-  if (b < 1) b = 1;
-  b = (b + MSDA_XCDS - 1) / MSDA_XCDS * MSDA_XCDS;
-  return (unsigned)b;
 }
 
 template <typename T>
@@ -262,29 +221,6 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
 #undef MSDA_POINT
   }
 }
-
-// <gradient row piece, value row piece> over the 16 bytes a lane holds: 4 fp32 FMAs, or 4 x v_dot2c_f32_bf16 on the raw
-// bf16 pairs (no bf16 -> f32 unpacking: 16 instead of 64 VALU per sampling point for the four corners)
-typedef unsigned int lw_raw_t __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-template <typename T> struct RowDot;
-template <> struct RowDot<float> {
-  static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += __uint_as_float(a[i]) * __uint_as_float(b[i]);
-    return s;
-  }
-};
-template <> struct RowDot<bf16_t> {
-  static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]), __builtin_bit_cast(bf16x2_t, b[i]), s, false);
-    return s;
-  }
-};
 
 // d_loc / d_attw only (the binned path computes d_value separately): same 16-lane-group decomposition as the forward
 // kernel (4 channels per lane, one 16-byte / 8-byte load per tap and lane, four (query, head) pairs per wave), the three
@@ -779,25 +715,27 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
   return n;
 }
 
-static int msda_levels(const int* spatial_hw, int L, int Nv, MsdaLevels& lv) {
-  if (L < 1 || L > MSDA_MAX_L) return GE_ERR_UNSUPPORTED;
-  long start = 0;
-  for (int l = 0; l < L; ++l) {
-    lv.H[l] = spatial_hw[2 * l]; lv.W[l] = spatial_hw[2 * l + 1]; lv.start[l] = (int)start;
-    if (lv.H[l] <= 0 || lv.W[l] <= 0) return GE_ERR_BAD_ARG;
-    start += (long)lv.H[l] * lv.W[l];
-  }
-  return start == Nv ? GE_OK : GE_ERR_BAD_ARG;
+
+// Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry); the
+// streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
+static int g_msda_mode = 3;
+extern "C" int ge_msda_mode(int mode) {
+  const int old = g_msda_mode;
+  if (mode >= 0) g_msda_mode = mode & 3;
+  return old;
 }
 
-extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, void* out,
-                           int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
+                           const float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
   if (!value || !spatial_hw || !loc || !attw || !out || B < 0 || Nv <= 0 || Nq < 0 || nH <= 0 || P <= 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
   if (e) return e;
   const long n_groups = (long)B * Nq * nH;
   if (n_groups == 0) return GE_OK;
+  if (dtype != GE_F32 && dtype != GE_BF16) return GE_ERR_UNSUPPORTED;
+  if ((g_msda_mode & 1) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv))
+    return msda_fwd_win_launch(value, lv, query_hw, n_qseg, loc, attw, out, B, Nv, Nq, nH, L, P, dtype, ge_stream(stream));
   if ((n_groups + 15) / 16 > (1L << 30) || (long)Nv * nH * 64 >= (1L << 31)) return GE_ERR_UNSUPPORTED;
   const unsigned blocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
   if (dtype == GE_F32)
@@ -839,7 +777,7 @@ extern "C" int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, in
 // the duration of ONE kernel, and HIP events recorded by the caller can only bracket the whole entry point).  Off by
 // default; when off the entry point records nothing and never synchronises.
 #define MSDA_NSTAGE 5
-static const char* const kMsdaStage[MSDA_NSTAGE] = {"msda_bwd_lw_k", "msda_hist_k<false>", "msda_scan_k+msda_segscan_k",
+static const char* const kMsdaStage[MSDA_NSTAGE] = {"msda_bwd_lw(_win)_k", "msda_hist_k<false>", "msda_scan_k+msda_segscan_k",
                                                     "msda_hist_k<true>", "msda_drain_k"};
 struct MsdaStageRec { int stage; hipEvent_t a, b; };
 static std::mutex g_msda_mu;
@@ -889,9 +827,9 @@ extern "C" int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launch
   return GE_OK;
 }
 
-extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out,
-                           float* d_value, float* d_loc, float* d_attw, void* workspace, size_t workspace_bytes,
-                           int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
+                           const float* attw, const void* d_out, float* d_value, float* d_loc, float* d_attw, void* workspace,
+                           size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
   if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || !d_loc || !d_attw) return GE_ERR_BAD_ARG;
   if (B < 0 || Nv <= 0 || Nq < 0 || nH <= 0 || P <= 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
@@ -925,7 +863,10 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const float
   hipEvent_t* ev = nullptr;
   { std::lock_guard<std::mutex> lk(g_msda_mu); if (g_msda_timing) ev = evs; }
   msda_mark(ev, 0, s);
-  {
+  if ((g_msda_mode & 2) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv)) {
+    e = msda_bwd_lw_win_launch(value, lv, query_hw, n_qseg, loc, attw, d_out, d_loc, d_attw, B, Nv, Nq, nH, L, P, dtype, s);
+    if (e) return e;
+  } else {
     const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);   // one trip per workgroup, in query order
     if (dtype == GE_F32)
       msda_bwd_lw_k<float><<<lblocks, 256, 0, s>>>((const float*)value, lv, loc, attw, (const float*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);

@@ -1,0 +1,403 @@
+// Deformable-attention sampling with LDS-staged value windows (gfx950): forward and the d_loc / d_attw backward pass.
+// Same op as msda_fwd_k / msda_bwd_lw_k in msda.hip (mmcv ms_deform_attn, reference call sites
+// depth/models/necks/hahi.py:279-289,316-325), different decomposition.
+//
+// Why: the streaming kernels are bound by the number of vector-memory (TA) instructions, ~25 cycles each per CU whatever
+// they fetch: per sampling point 4 row gathers + 2 broadcast loads of its location / weight.  Queries that
+// are neighbours in the image sample neighbouring value rows (self-attention: reference point = own pixel centre;
+// cross-attention: a smooth function of the position, hahi.py:294-302), so a TILE of queries touches a compact window of
+// each level — each row of it hundreds of times.  Here a workgroup owns (image, head, 16x16 query tile) and, level by level:
+//   A  one sampling point per lane: coalesced 8-byte / 4-byte loads of loc / attw (2 TA instructions per 8 points
+//      instead of 16), tap coordinates, bounding box of the taps of the whole tile (wave min/max + 4 LDS atomics);
+//   B  if the box has <= CAP rows it is copied into LDS once (128-byte rows of this head, 16 bytes per lane);
+//   C  the 4 x 8 x 256 taps are ds_read_b128 reads of the window (LDS: 256 B/clk/CU instead of the 64 B/clk/CU vector
+//      L1 path); point data reach the 8 lanes of a (query, head) group by ds_bpermute.  A box that does not fit (scattered
+//      reference points after training, coarse-level queries sampling the finest level) takes the same code on global
+//      pointers — a per-(tile, level) decision, so correctness never depends on locality.
+// No MFMA: a gather, not a contraction.
+#include "msda.h"
+#include <limits.h>
+
+#define MW_BYTES 51200                    // LDS window: 400 bf16 rows / 200 fp32 rows of 64 channels; 3 workgroups per CU
+#define MW_QPG 4                          // queries per lane group (accumulators live in registers across the level loop)
+
+struct MsdaQGrid {                        // query tiling: segments of (H, W) queries in raster order (the levels for
+  int nseg;                               // self-attention, one 176x560 map for the cross-attention; 1 x Nq if unknown)
+  int H[MSDA_MAX_L], W[MSDA_MAX_L], start[MSDA_MAX_L];
+  int tiles_x[MSDA_MAX_L], tile_first[MSDA_MAX_L + 1];
+};
+
+template <typename T> struct WinGeom {
+  static constexpr int CPL = Lanes<T>::CPL;          // channels per lane (16 bytes)
+  static constexpr int G = 64 / CPL;                 // lanes per (query, head) group = per value row
+  static constexpr int NG = 256 / G;                 // groups per workgroup
+  static constexpr int TQ = NG * MW_QPG;             // queries per tile: 256 (bf16), 128 (fp32)
+  static constexpr int TQW = 16, TQH = TQ / 16;      // 16 x 16 / 8 x 16 (H x W)
+  static constexpr int CAP = MW_BYTES / (64 * (int)sizeof(T));
+};
+
+// Tap geometry of one sampling point, branch-free: addresses clamped into the map, out-of-range corners carry zero
+// weight (identical arithmetic to msda_fwd_k / msda_bwd_lw_k).
+struct MwTap { int xa, xb, ya, yb; float ax, ay; bool kxa, kxb, kya, kyb; };
+__device__ __forceinline__ MwTap mw_tap(float x, float y, int Wl, int Hl) {
+  MwTap t;
+  const float xc = fminf(fmaxf(x, -1.f), (float)Wl), yc = fminf(fmaxf(y, -1.f), (float)Hl);
+  const float xf = floorf(xc), yf = floorf(yc);
+  const int x0 = (int)xf, y0 = (int)yf;
+  t.ax = xc - xf; t.ay = yc - yf;
+  t.xa = min(max(x0, 0), Wl - 1); t.xb = min(max(x0 + 1, 0), Wl - 1);
+  t.ya = min(max(y0, 0), Hl - 1); t.yb = min(max(y0 + 1, 0), Hl - 1);
+  t.kxa = x0 >= 0; t.kxb = x0 + 1 < Wl; t.kya = y0 >= 0; t.kyb = y0 + 1 < Hl;
+  return t;
+}
+__device__ __forceinline__ int mw_wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int mw_wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Workgroup -> (image, head, tile).  XCD x (= blockIdx % 8) works on a contiguous eighth of the (image, tile, head) range, so
+// the tiles that share value rows meet in one L2.
+struct MwJob { int b, head, seg, ty, tx; bool live; };
+__device__ __forceinline__ MwJob mw_job(const MsdaQGrid& qg, int nH, int B) {
+  MwJob j;
+  const int ntiles = qg.tile_first[qg.nseg];
+  const long idx = msda_xcd_block(blockIdx.x, gridDim.x);
+  const long total = (long)B * ntiles * nH;
+  j.live = idx < total;
+  const long i = j.live ? idx : 0;
+  j.head = (int)(i % nH);
+  const long bt = i / nH;
+  const int tile = (int)(bt % ntiles);
+  j.b = (int)(bt / ntiles);
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < MSDA_MAX_L; ++k) s += (k < qg.nseg && tile >= qg.tile_first[k]) ? 1 : 0;
+  j.seg = s;
+  const int t = tile - qg.tile_first[s];
+  j.ty = t / qg.tiles_x[s];
+  j.tx = t - j.ty * qg.tiles_x[s];
+  return j;
+}
+
+// Phases A + B for one level.  Each lane with sub < 8 owns sampling point `sub` of the MW_QPG queries of its group:
+// px / py = pixel coordinates, pw = attention weight (0 for a point that samples nothing or a query outside the map).
+// Returns true when the window was staged; box = {xmin, ymin, width, rows}.
+template <typename T>
+__device__ __forceinline__ bool mw_stage(const T* __restrict__ vl, int Wl, int Hl, int nh64, const float* __restrict__ loc,
+                                         const float* __restrict__ attw, const int* qbase, const bool* qok, int l, int P,
+                                         float* px, float* py, float* pw, uint4* win, int* s_box, int box[4]) {
+  constexpr int G = WinGeom<T>::G, NG = WinGeom<T>::NG, CAP = WinGeom<T>::CAP;
+  const int sub = threadIdx.x % G;
+  int xmin = INT_MAX, ymin = INT_MAX, xmax = -1, ymax = -1;
+  if (threadIdx.x == 0) { s_box[0] = INT_MAX; s_box[1] = INT_MAX; s_box[2] = -1; s_box[3] = -1; }
+#pragma unroll
+  for (int i = 0; i < MW_QPG; ++i) {
+    float x = -2.f, y = -2.f, w = 0.f;
+    if (sub < 8 && qok[i]) {
+      const long o = (long)qbase[i] + l * P + sub;
+      const float2 xy = *(const float2*)(loc + 2 * o);
+      w = attw[o];
+      x = xy.x * (float)Wl - 0.5f; y = xy.y * (float)Hl - 0.5f;
+    }
+    const bool in = y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl;     // NaN-safe: a NaN location samples nothing
+    if (!in) { x = -2.f; y = -2.f; w = 0.f; }
+    px[i] = x; py[i] = y; pw[i] = w;
+    if (in) {
+      const MwTap t = mw_tap(x, y, Wl, Hl);
+      xmin = min(xmin, t.xa); xmax = max(xmax, t.xb); ymin = min(ymin, t.ya); ymax = max(ymax, t.yb);
+    }
+  }
+  xmin = mw_wave_min(xmin); ymin = mw_wave_min(ymin); xmax = mw_wave_max(xmax); ymax = mw_wave_max(ymax);
+  __syncthreads();                                            // s_box initialised; previous level's window reads done
+  if ((threadIdx.x & 63) == 0 && xmax >= 0) {
+    atomicMin(&s_box[0], xmin); atomicMin(&s_box[1], ymin); atomicMax(&s_box[2], xmax); atomicMax(&s_box[3], ymax);
+  }
+  __syncthreads();
+  xmin = s_box[0]; ymin = s_box[1]; xmax = s_box[2]; ymax = s_box[3];
+  const bool any = xmax >= 0;
+  const int bw = any ? xmax - xmin + 1 : 0, bh = any ? ymax - ymin + 1 : 0;
+  const int rows = bw * bh;
+  box[0] = any ? xmin : 0; box[1] = any ? ymin : 0; box[2] = bw; box[3] = rows;
+  const bool staged = any && rows <= CAP;
+  if (staged) {
+    const T* src = vl + sub * WinGeom<T>::CPL;
+    for (int r = threadIdx.x / G; r < rows; r += NG) {
+      const int ry = r / bw, rx = r - ry * bw;
+      win[r * G + sub] = *(const uint4*)(src + (long)((ymin + ry) * Wl + xmin + rx) * nh64);
+    }
+  }
+  __syncthreads();
+  return staged;
+}
+
+template <typename T> struct MwAcc;
+template <> struct MwAcc<bf16_t> {
+  static __device__ __forceinline__ void fma4(float* acc, const uint4& a, const uint4& b, const uint4& c, const uint4& d,
+                                              float w00, float w01, float w10, float w11) {
+    const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w}, rc[4] = {c.x, c.y, c.z, c.w}, rd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] += w00 * __uint_as_float(ra[i] << 16) + w01 * __uint_as_float(rb[i] << 16) + w10 * __uint_as_float(rc[i] << 16) +
+                    w11 * __uint_as_float(rd[i] << 16);
+      acc[2 * i + 1] += w00 * __uint_as_float(ra[i] & 0xffff0000u) + w01 * __uint_as_float(rb[i] & 0xffff0000u) +
+                        w10 * __uint_as_float(rc[i] & 0xffff0000u) + w11 * __uint_as_float(rd[i] & 0xffff0000u);
+    }
+  }
+};
+template <> struct MwAcc<float> {
+  static __device__ __forceinline__ void fma4(float* acc, const uint4& a, const uint4& b, const uint4& c, const uint4& d,
+                                              float w00, float w01, float w10, float w11) {
+    const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w}, rc[4] = {c.x, c.y, c.z, c.w}, rd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i] += w00 * __uint_as_float(ra[i]) + w01 * __uint_as_float(rb[i]) + w10 * __uint_as_float(rc[i]) + w11 * __uint_as_float(rd[i]);
+  }
+};
+
+// Shared prologue: the MW_QPG queries of this lane group.  Local query index g + NG * i inside the TQH x TQW tile.
+template <typename T>
+__device__ __forceinline__ void mw_queries(const MsdaQGrid& qg, const MwJob& job, int Nq, int nH, int LP, int* qbase, int* qrow, bool* qok) {
+  constexpr int G = WinGeom<T>::G, NG = WinGeom<T>::NG, TQW = WinGeom<T>::TQW, TQH = WinGeom<T>::TQH;
+  const int g = threadIdx.x / G;
+  const int Hs = qg.H[job.seg], Ws = qg.W[job.seg];
+#pragma unroll
+  for (int i = 0; i < MW_QPG; ++i) {
+    const int qi = g + NG * i;
+    const int y = job.ty * TQH + qi / TQW, x = job.tx * TQW + qi % TQW;
+    qok[i] = job.live && y < Hs && x < Ws;
+    const long q = qg.start[job.seg] + (long)(qok[i] ? y : 0) * Ws + (qok[i] ? x : 0);
+    qrow[i] = (int)(((long)job.b * Nq + q) * nH + job.head);    // (b, q, head) index: * 64 = output / gradient row
+    qbase[i] = qrow[i] * LP;                                     // * 2 = loc offset, * 1 = attw offset (launcher: < 2^31)
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ value, MsdaLevels lv, MsdaQGrid qg,
+                                                      const float* __restrict__ loc, const float* __restrict__ attw,
+                                                      T* __restrict__ out, int B, int Nv, int Nq, int nH, int L, int P) {
+  constexpr int CPL = WinGeom<T>::CPL, G = WinGeom<T>::G;
+  __shared__ uint4 win[MW_BYTES / 16];
+  __shared__ int s_box[4];
+  const int sub = threadIdx.x % G;
+  const MwJob job = mw_job(qg, nH, B);
+  const int nh64 = nH * 64;
+  int qbase[MW_QPG], qrow[MW_QPG];
+  bool qok[MW_QPG];
+  mw_queries<T>(qg, job, Nq, nH, L * P, qbase, qrow, qok);
+  float acc[MW_QPG][CPL];
+#pragma unroll
+  for (int i = 0; i < MW_QPG; ++i)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) acc[i][c] = 0.f;
+  const T* vb = value + ((long)job.b * Nv * nH + job.head) * 64;
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const T* vl = vb + (long)lv.start[l] * nH * 64;
+    float px[MW_QPG], py[MW_QPG], pw[MW_QPG];
+    int box[4];
+    const bool staged = mw_stage<T>(vl, Wl, Hl, nh64, loc, attw, qbase, qok, l, P, px, py, pw, win, s_box, box);
+    if (box[3] == 0) continue;                                  // nothing in this tile samples level l (uniform)
+    const int x0w = box[0], y0w = box[1], bw = box[2];
+    const uint4* gsrc = (const uint4*)(vl + sub * CPL);
+#pragma unroll
+    for (int i = 0; i < MW_QPG; ++i) {
+#pragma unroll 1
+      for (int p = 0; p < 8; ++p) {
+        const float x = __shfl(px[i], p, G), y = __shfl(py[i], p, G), wgt = __shfl(pw[i], p, G);
+        const bool in = x > -1.5f;
+        const MwTap t = mw_tap(x, y, Wl, Hl);
+        const float bx = 1.f - t.ax, by = 1.f - t.ay;
+        const float wxa = (in && t.kxa) ? bx : 0.f, wxb = (in && t.kxb) ? t.ax : 0.f;
+        const float wya = t.kya ? by : 0.f, wyb = t.kyb ? t.ay : 0.f;
+        uint4 r00, r01, r10, r11;
+        if (staged) {
+          // a point that samples nothing reads row 0 of the window (valid data) with zero weights
+          const int ra = in ? (t.ya - y0w) * bw - x0w : 0, rb = in ? (t.yb - y0w) * bw - x0w : 0;
+          const int xa = in ? t.xa : 0, xb = in ? t.xb : 0;
+          r00 = win[(ra + xa) * G + sub]; r01 = win[(ra + xb) * G + sub];
+          r10 = win[(rb + xa) * G + sub]; r11 = win[(rb + xb) * G + sub];
+        } else {
+          const long s16 = nh64 * (int)sizeof(T) / 16;             // row stride in 16-byte units
+          r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
+          r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
+        }
+        MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, wya * wxa * wgt, wya * wxb * wgt, wyb * wxa * wgt, wyb * wxb * wgt);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MW_QPG; ++i)
+    if (qok[i]) VecL<T>::st(out + (long)qrow[i] * 64 + sub * CPL, acc[i]);
+}
+
+// d_loc / d_attw: per point the four <gradient row, value row> dot products (raw bf16 pairs through v_dot2c), the three
+// sums (weight, d/dx, d/dy) reduce-scattered over the lane group exactly as in msda_bwd_lw_k.
+template <typename T>
+__global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ value, MsdaLevels lv, MsdaQGrid qg,
+                                                         const float* __restrict__ loc, const float* __restrict__ attw,
+                                                         const T* __restrict__ gout, float* __restrict__ d_loc,
+                                                         float* __restrict__ d_attw, int B, int Nv, int Nq, int nH, int L, int P) {
+  constexpr int CPL = WinGeom<T>::CPL, G = WinGeom<T>::G;
+  __shared__ uint4 win[MW_BYTES / 16];
+  __shared__ int s_box[4];
+  const int sub = threadIdx.x % G;
+  const MwJob job = mw_job(qg, nH, B);
+  const int nh64 = nH * 64;
+  const int LP = L * P;
+  int qbase[MW_QPG], qrow[MW_QPG];
+  bool qok[MW_QPG];
+  mw_queries<T>(qg, job, Nq, nH, LP, qbase, qrow, qok);
+  lw_raw_t go[MW_QPG];
+#pragma unroll
+  for (int i = 0; i < MW_QPG; ++i) go[i] = *(const lw_raw_t*)(gout + (long)qrow[i] * 64 + sub * CPL);   // clamped to a valid row when !qok
+  const T* vb = value + ((long)job.b * Nv * nH + job.head) * 64;
+  for (int l = 0; l < L; ++l) {
+    const int Hl = lv.H[l], Wl = lv.W[l];
+    const T* vl = vb + (long)lv.start[l] * nH * 64;
+    float px[MW_QPG], py[MW_QPG], pw[MW_QPG];
+    int box[4];
+    const bool staged = mw_stage<T>(vl, Wl, Hl, nh64, loc, attw, qbase, qok, l, P, px, py, pw, win, s_box, box);
+    const bool empty = box[3] == 0;                             // uniform: every gradient of this level is zero
+    const int x0w = box[0], y0w = box[1], bw = box[2];
+    const lw_raw_t* gsrc = (const lw_raw_t*)(vl + sub * CPL);
+    const lw_raw_t* lwin = (const lw_raw_t*)win;
+#pragma unroll
+    for (int i = 0; i < MW_QPG; ++i) {
+      float part[24];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        float sv = 0.f, sx = 0.f, sy = 0.f;
+        if (!empty) {
+          const float x = __shfl(px[i], p, G), y = __shfl(py[i], p, G), wgt = __shfl(pw[i], p, G);
+          const bool in = x > -1.5f;
+          const MwTap t = mw_tap(x, y, Wl, Hl);
+          const float bx = 1.f - t.ax, by = 1.f - t.ay;
+          lw_raw_t r00, r01, r10, r11;
+          if (staged) {
+            const int ra = in ? (t.ya - y0w) * bw - x0w : 0, rb = in ? (t.yb - y0w) * bw - x0w : 0;
+            const int xa = in ? t.xa : 0, xb = in ? t.xb : 0;
+            r00 = lwin[(ra + xa) * G + sub]; r01 = lwin[(ra + xb) * G + sub];
+            r10 = lwin[(rb + xa) * G + sub]; r11 = lwin[(rb + xb) * G + sub];
+          } else {
+            const long s16 = nh64 * (int)sizeof(T) / 16;
+            r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
+            r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
+          }
+          float d00 = RowDot<T>::dot(go[i], r00), d01 = RowDot<T>::dot(go[i], r01);
+          float d10 = RowDot<T>::dot(go[i], r10), d11 = RowDot<T>::dot(go[i], r11);
+          const bool k_xa = in && t.kxa, k_xb = in && t.kxb;
+          d00 = (t.kya && k_xa) ? d00 : 0.f; d01 = (t.kya && k_xb) ? d01 : 0.f;
+          d10 = (t.kyb && k_xa) ? d10 : 0.f; d11 = (t.kyb && k_xb) ? d11 : 0.f;
+          sv = by * bx * d00 + by * t.ax * d01 + t.ay * bx * d10 + t.ay * t.ax * d11;
+          sx = (by * (d01 - d00) + t.ay * (d11 - d10)) * (wgt * (float)Wl);
+          sy = (bx * (d10 - d00) + t.ax * (d11 - d01)) * (wgt * (float)Hl);
+        }
+        part[p] = sv; part[8 + p] = sx; part[16 + p] = sy;
+      }
+      // 24 partial sums per (query, level), reduce-scattered over the lane group (24 -> 12 -> 6 -> 3 values per lane)
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const bool up = sub & (G / 2);
+        const float send = up ? part[k] : part[k + 12], keep = up ? part[k + 12] : part[k];
+        part[k] = keep + __shfl_xor(send, G / 2, 64);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const bool up = sub & (G / 4);
+        const float send = up ? part[k] : part[k + 6], keep = up ? part[k + 6] : part[k];
+        part[k] = keep + __shfl_xor(send, G / 4, 64);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const bool up = sub & (G / 8);
+        const float send = up ? part[k] : part[k + 3], keep = up ? part[k + 3] : part[k];
+        part[k] = keep + __shfl_xor(send, G / 8, 64);
+      }
+      if (G == 16) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) part[k] += __shfl_xor(part[k], 1, 64);
+      }
+      if (qok[i] && (G == 8 || (sub & 1) == 0)) {
+        const int base = ((sub / (G / 2)) & 1) * 12 + ((sub / (G / 4)) & 1) * 6 + ((sub / (G / 8)) & 1) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int idx = base + k;
+          const int which = idx >> 3, j = l * 8 + (idx & 7);
+          if (which == 0) d_attw[(long)qbase[i] + j] = part[k];
+          else d_loc[((long)qbase[i] + j) * 2 + (which - 1)] = part[k];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ host side
+static int mw_qgrid(const int* query_hw, int n_qseg, int Nq, int tqh, int tqw, MsdaQGrid& qg) {
+  if (!query_hw || n_qseg <= 0 || n_qseg > MSDA_MAX_L) return GE_ERR_UNSUPPORTED;
+  qg.nseg = n_qseg;
+  long start = 0;
+  int n = 0;
+  for (int s = 0; s < MSDA_MAX_L; ++s) {
+    const bool used = s < n_qseg;
+    qg.H[s] = used ? query_hw[2 * s] : 1; qg.W[s] = used ? query_hw[2 * s + 1] : 1; qg.start[s] = (int)start;
+    if (qg.H[s] <= 0 || qg.W[s] <= 0) return GE_ERR_BAD_ARG;
+    qg.tile_first[s] = n;
+    qg.tiles_x[s] = (qg.W[s] + tqw - 1) / tqw;
+    if (used) {
+      start += (long)qg.H[s] * qg.W[s];
+      n += qg.tiles_x[s] * ((qg.H[s] + tqh - 1) / tqh);
+    }
+  }
+  qg.tile_first[MSDA_MAX_L] = n;
+  for (int s = n_qseg; s <= MSDA_MAX_L; ++s) qg.tile_first[s] = n;
+  return start == Nq ? GE_OK : GE_ERR_BAD_ARG;
+}
+
+// The window kernels handle P == 8 (the HAHI configuration) and query geometries given as (H, W) segments; a query set
+// without geometry is tiled as one row, which only loses the locality (the global fallback then serves most tiles).
+int msda_win_supported(int B, int Nq, int nH, int L, int P, int Nv) {
+  return P == 8 && L >= 1 && L <= MSDA_MAX_L && (long)Nv * nH * 64 < (1L << 31) && (long)B * Nq * nH * L * P < (1L << 31);
+}
+
+int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc, const float* attw,
+                        void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, hipStream_t s) {
+  MsdaQGrid qg;
+  const bool f32 = dtype == GE_F32;
+  int e = mw_qgrid(query_hw, n_qseg, Nq, f32 ? WinGeom<float>::TQH : WinGeom<bf16_t>::TQH, 16, qg);
+  if (e) return e;
+  const long total = (long)B * qg.tile_first[qg.nseg] * nH;
+  if (total <= 0) return GE_OK;
+  if (total > (1L << 30)) return GE_ERR_UNSUPPORTED;
+  const unsigned blocks = msda_grid(total, 1);
+  if (f32)
+    msda_fwd_win_k<float><<<blocks, 256, 0, s>>>((const float*)value, lv, qg, loc, attw, (float*)out, B, Nv, Nq, nH, L, P);
+  else
+    msda_fwd_win_k<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)value, lv, qg, loc, attw, (bf16_t*)out, B, Nv, Nq, nH, L, P);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+int msda_bwd_lw_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc,
+                           const float* attw, const void* gout, float* d_loc, float* d_attw, int B, int Nv, int Nq, int nH, int L,
+                           int P, int dtype, hipStream_t s) {
+  MsdaQGrid qg;
+  const bool f32 = dtype == GE_F32;
+  int e = mw_qgrid(query_hw, n_qseg, Nq, f32 ? WinGeom<float>::TQH : WinGeom<bf16_t>::TQH, 16, qg);
+  if (e) return e;
+  const long total = (long)B * qg.tile_first[qg.nseg] * nH;
+  if (total <= 0) return GE_OK;
+  if (total > (1L << 30)) return GE_ERR_UNSUPPORTED;
+  const unsigned blocks = msda_grid(total, 1);
+  if (f32)
+    msda_bwd_lw_win_k<float><<<blocks, 256, 0, s>>>((const float*)value, lv, qg, loc, attw, (const float*)gout, d_loc, d_attw, B, Nv, Nq, nH, L, P);
+  else
+    msda_bwd_lw_win_k<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)value, lv, qg, loc, attw, (const bf16_t*)gout, d_loc, d_attw, B, Nv, Nq, nH, L, P);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}

@@ -50,7 +50,7 @@ class MultiScaleDeformableAttention(BaseModule):
         xavier_init(self.output_proj, distribution='uniform', bias=0.)
         self._is_init = True
 
-    def _attend(self, query, value, reference_points, spatial_shapes, key_padding_mask=None):
+    def _attend(self, query, value, reference_points, spatial_shapes, key_padding_mask=None, query_shapes=None):
         """query (B,Nq,C) with the positional embedding already added, value (B,Nv,C) -> output_proj(sampled) (B,Nq,C).
 
         The two query linears run as ONE GEMM on concatenated weights (their input is the same 0.4-0.8 GB tensor), and
@@ -72,11 +72,13 @@ class MultiScaleDeformableAttention(BaseModule):
         raw = bricks.linear_tokens(query, w, b)               # (B, Nq, nH*L*P*2 + nH*L*P)
         # sampling locations / weights are fp32 (pixel coordinates up to ~1000 need > 8 mantissa bits)
         loc, weights = msda_prepare(raw, reference_points.expand(bs, num_query, L, 2), spatial_shapes, nH, L, P)
-        out = ms_deform_attn(value, spatial_shapes, loc, weights)
+        out = ms_deform_attn(value, spatial_shapes, loc, weights, query_shapes)
         return self.output_proj(out)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, query_shapes=None, **kwargs):
+        """mmcv MultiScaleDeformableAttention.forward; ``query_shapes`` (extension, optional): the queries as (H, W) maps in
+        raster order, e.g. ``spatial_shapes`` itself for self-attention — enables the 2-D tiled sampling kernels."""
         if value is None:
             value = query
         if identity is None:
@@ -85,7 +87,7 @@ class MultiScaleDeformableAttention(BaseModule):
             query = query + query_pos.to(query.dtype)
         if not self.batch_first:
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
-        out = self._attend(query, value, reference_points, spatial_shapes, key_padding_mask)
+        out = self._attend(query, value, reference_points, spatial_shapes, key_padding_mask, query_shapes)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         return self.dropout(out) + identity
@@ -95,7 +97,7 @@ class MultiScaleDeformableAttention(BaseModule):
         result returned as ``torch.cat([to_map(dropout(out) + identity), concat_with], 1)``.  The two layout changes carry
         the position add, the dropout, the residual and the concat write (gedepth_amd/csrc/neck.hip)."""
         query = tokens_from_map(fmap, pos_map)
-        out = self._attend(query, value, reference_points, spatial_shapes)
+        out = self._attend(query, value, reference_points, spatial_shapes, query_shapes=[tuple(fmap.shape[2:])])
         p = self.dropout.p if self.training else 0.0
         return concat_tokens_map(out, concat_with, identity=fmap, tokens_first=True, p_drop=p)
 
@@ -176,7 +178,7 @@ class HAHIHeteroNeck(BaseModule):
         if self.self_att:
             ref = self._pixel_centres(shapes, dev).expand(bs, -1, -1, -1)
             src = self.self_attn(src_flatten, value=None, identity=None, query_pos=pos_flatten,
-                                 reference_points=ref, spatial_shapes=shapes)
+                                 reference_points=ref, spatial_shapes=shapes, query_shapes=shapes)
         else:
             src = src_flatten
 

@@ -22,9 +22,10 @@ SIGNATURES = {
     'ge_window_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'ge_window_attn_bwd_workspace': (_sz, [_i, _i, _i, _i]),
     'ge_window_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
-    'ge_msda_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_fwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_mode': (_i, [_i]),
     'ge_msda_bwd_workspace': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
-    'ge_msda_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_bwd': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_plan': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_timing': (_i, [_i]),
     'ge_msda_bwd_timing_read': (_i, [_i, _vp, _vp, _vp, _i]),

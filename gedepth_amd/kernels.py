@@ -133,10 +133,24 @@ def _levels(spatial_shapes):
     return (ctypes.c_int * len(flat))(*flat), len(flat) // 2
 
 
+def _query_grid(query_shapes, Nq):
+    if query_shapes is None:
+        return None, 0
+    flat = [int(v) for hw in query_shapes for v in hw]
+    assert sum(flat[i] * flat[i + 1] for i in range(0, len(flat), 2)) == Nq, (query_shapes, Nq)
+    return ctypes.cast((ctypes.c_int * len(flat))(*flat), ctypes.c_void_p), len(flat) // 2
+
+
+def msda_mode(mode=-1):
+    """Kernel-selection knob of the deformable-attention ops (bit 0: window forward, bit 1: window d_loc/d_attw); returns
+    the previous mode."""
+    return int(hip.lib().ge_msda_mode(int(mode)))
+
+
 class _MSDeformAttn(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, value, loc, attw, spatial_shapes):
+    def forward(ctx, value, loc, attw, spatial_shapes, query_shapes):
         value = _c(value)
         loc = _c(loc.to(_f32))
         attw = _c(attw.to(_f32))
@@ -145,13 +159,15 @@ class _MSDeformAttn(torch.autograd.Function):
         _, Nq, _, L, P, _ = loc.shape
         arr, nl = _levels(spatial_shapes)
         assert nl == L
+        qarr, nq = _query_grid(query_shapes, Nq)
         out = torch.empty(B, Nq, nH * D, device=value.device, dtype=value.dtype)
         nbytes = value.numel() * _es(value) + loc.numel() * 4 + attw.numel() * 4 + out.numel() * _es(out)
-        PROFILER.run(f'msda_fwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(
-            hip.lib().ge_msda_fwd(hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), hip.ptr(loc), hip.ptr(attw),
+        PROFILER.run(f'msda_fwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}{" win" if nq else ""}]', nbytes, lambda: hip.check(
+            hip.lib().ge_msda_fwd(hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), qarr, nq, hip.ptr(loc), hip.ptr(attw),
                                   hip.ptr(out), B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()), 'ge_msda_fwd'))
         ctx.save_for_backward(value, loc, attw)
         ctx.shapes = tuple(tuple(int(v) for v in hw) for hw in spatial_shapes)
+        ctx.qshapes = None if query_shapes is None else tuple(tuple(int(v) for v in hw) for hw in query_shapes)
         return out
 
     @staticmethod
@@ -161,6 +177,7 @@ class _MSDeformAttn(torch.autograd.Function):
         _, Nq, _, L, P, _ = loc.shape
         d_out = _c(d_out.to(value.dtype))
         arr, _ = _levels(ctx.shapes)
+        qarr, nq = _query_grid(ctx.qshapes, Nq)
         d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
         d_loc = torch.empty_like(loc)
         d_attw = torch.empty_like(attw)
@@ -175,15 +192,17 @@ class _MSDeformAttn(torch.autograd.Function):
             la_b = (loc.numel() + attw.numel()) * 4
             PROFILER.add_stage_bytes((lw_b, la_b, 0, la_b, d_out.numel() * _es(d_out) + d_value.numel() * 4))
         PROFILER.run(f'msda_bwd[B{B} Nq{Nq} Nv{Nv} {_tag(value)}{" binned" if ws_bytes else ""}]', nbytes, lambda: hip.check(
-            lib.ge_msda_bwd(hip.ptr(value), shapes_p, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
+            lib.ge_msda_bwd(hip.ptr(value), shapes_p, qarr, nq, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
                             hip.ptr(d_value), hip.ptr(d_loc), hip.ptr(d_attw), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P,
                             hip.dtype_code(value), hip.stream()), 'ge_msda_bwd'))
-        return d_value.to(value.dtype), d_loc, d_attw, None
+        return d_value.to(value.dtype), d_loc, d_attw, None, None
 
 
-def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights):
-    """value (B,Nv,nH,64), loc (B,Nq,nH,L,P,2) in [0,1], attw (B,Nq,nH,L,P) -> (B,Nq,nH*64)."""
-    return _MSDeformAttn.apply(value, sampling_locations, attention_weights, spatial_shapes)
+def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights, query_shapes=None):
+    """value (B,Nv,nH,64), loc (B,Nq,nH,L,P,2) in [0,1], attw (B,Nq,nH,L,P) -> (B,Nq,nH*64).
+    ``query_shapes``: the queries as a list of (H, W) maps in raster order (sum H*W == Nq) — lets the kernels tile them 2-D
+    and sample from LDS-staged value windows (csrc/msda_win.hip); None = streaming kernels.  Same results either way."""
+    return _MSDeformAttn.apply(value, sampling_locations, attention_weights, spatial_shapes, query_shapes)
 
 
 class _MSDAPrep(torch.autograd.Function):

@@ -72,9 +72,16 @@ int ge_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias
  *   loc            (B, Nq, nH, L, P, 2)   f32     normalised (x,y) in [0,1]
  *   attw           (B, Nq, nH, L, P)      f32
  *   out            (B, Nq, nH*64)         dtype
+ *   query_hw       host int[2*n_qseg] or NULL: the query set as n_qseg (H, W) maps in raster order (sum H*W == Nq) — the
+ *                  value levels themselves for the self-attention (hahi.py:279-289), the single 176x560 map for the
+ *                  cross-attention (:303-325).  With it (and P == 8) the kernels tile the queries 2-D and serve the taps
+ *                  from LDS-staged value windows (csrc/msda_win.hip); NULL selects the streaming kernels.  Same results.
  */
-int ge_msda_fwd(const void* value, const int* spatial_hw, const float* loc, const float* attw, void* out,
-                int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+int ge_msda_fwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
+                const float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+/* Kernel selection knob (A/B timing, tests): bit 0 = window forward, bit 1 = window d_loc/d_attw; mode < 0 only queries.
+ * Returns the previous mode (default 3). */
+int ge_msda_mode(int mode);
 
 /* Backward.  d_value (B,Nv,nH,64) is ALWAYS f32 and must be zero-filled by the caller; d_loc / d_attw are fully
  * written.  `workspace` (>= ge_msda_bwd_workspace(...) bytes, caller-owned scratch) enables the binned scatter
@@ -84,7 +91,8 @@ size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, int Nq, int n
 /* Introspection (no device work): out4 = {binned path available, histogram split (1 = all heads per workgroup,
  * nH = one head per workgroup for maps whose tile count exceeds one LDS histogram), value tiles, bins}. */
 int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int* out4);
-int ge_msda_bwd(const void* value, const int* spatial_hw, const float* loc, const float* attw,
+int ge_msda_bwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg,
+                const float* loc, const float* attw,
                 const void* d_out, float* d_value, float* d_loc, float* d_attw,
                 void* workspace, size_t workspace_bytes,
                 int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);

@@ -143,7 +143,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().ge_abi_version() == 1
+    assert hip.lib().ge_abi_version() == 2
     # argument validation happens before any launch, so these are safe without a GPU
     assert hip.lib().ge_bilinear_fwd(None, None, 1, 1, 4, 4, 8, 8, 0, 0, None) == 10001
     assert hip.lib().ge_window_attn_bwd_workspace(2, 11, 35, 3) > 0
@@ -195,16 +195,25 @@ def test_tuning_tables_are_lookup_only(monkeypatch, tmp_path):
     shapes = [r for r in rows if r[0] != 'Validator']
     assert len(shapes) >= 60 and any('StridedBatched' in r[0] for r in shapes)
     monkeypatch.delenv('MIOPEN_USER_DB_PATH', raising=False)
-    monkeypatch.setenv('TMPDIR', str(tmp_path))
-    import tempfile
-    tempfile.tempdir = None
+    monkeypatch.setenv('XDG_CACHE_HOME', str(tmp_path))
     try:
         assert tuning.use_miopen_find_db() is True
         dst = os.environ['MIOPEN_USER_DB_PATH']
-        assert dst.startswith(str(tmp_path)) and sorted(os.listdir(dst)) == sorted(
-            f for f in os.listdir(tuning.MIOPEN_DB) if f.endswith('db.txt'))
+        files = sorted(f for f in os.listdir(tuning.MIOPEN_DB) if f.endswith('db.txt'))
+        assert dst.startswith(str(tmp_path)) and sorted(os.listdir(dst)) == files
+        # a private (0700, user-owned) directory, never the shared tempdir; stale / foreign content is always rewritten
+        assert os.stat(dst).st_mode & 0o777 == 0o700 and os.stat(os.path.dirname(dst)).st_mode & 0o777 == 0o700
+        with open(os.path.join(dst, files[0]), 'w') as fh:
+            fh.write('tampered')
+        os.environ.pop('MIOPEN_USER_DB_PATH')
+        assert tuning.use_miopen_find_db() is True
+        assert open(os.path.join(dst, files[0]), 'rb').read() == open(os.path.join(tuning.MIOPEN_DB, files[0]), 'rb').read()
+        os.environ.pop('MIOPEN_USER_DB_PATH')
+        os.rename(dst, dst + '.real')
+        os.symlink(dst + '.real', dst)
+        with pytest.raises(RuntimeError, match='symlink'):
+            tuning.use_miopen_find_db()
     finally:
-        tempfile.tempdir = None
         os.environ.pop('MIOPEN_USER_DB_PATH', None)
     assert tuning.use_tuned_gemms('off') is False
     with pytest.raises(ValueError):

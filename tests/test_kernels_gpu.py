@@ -226,6 +226,81 @@ def test_msda_fp32_fwd_bwd(dev, binned, shapes, monkeypatch):
     close_scaled(lg.grad, lc.grad, rel=2e-4, what='d loc')
 
 
+def _coherent_locations(B, qshapes, shapes, seed, spread=0.0, jitter=2.5):
+    """Sampling locations like the HAHI neck produces: reference point = the query's own (normalised) pixel centre, offsets
+    of a few pixels of each level; ``spread`` adds a fraction of scattered points (anywhere, incl. outside the map)."""
+    g = gen(seed)
+    refs = []
+    for h, w in qshapes:
+        gy, gx = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+    ref = torch.cat(refs, 0)                                              # (Nq, 2)
+    Nq = ref.shape[0]
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)   # (L, 2)
+    off = jitter * torch.randn(B, Nq, 8, len(shapes), 8, 2, generator=g)
+    loc = ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+    if spread > 0:
+        wild = torch.rand(B, Nq, 8, len(shapes), 8, 1, generator=g) < spread
+        loc = torch.where(wild, torch.rand(loc.shape, generator=g) * 1.4 - 0.2, loc)
+    aw = torch.rand(B, Nq, 8, len(shapes), 8, generator=g).flatten(-2).softmax(-1).view(B, Nq, 8, len(shapes), 8)
+    return loc, aw
+
+
+@pytest.mark.parametrize('case', ['self', 'cross', 'scattered', 'ragged'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_msda_window_kernels(dev, case, dtype):
+    """The LDS-window kernels (csrc/msda_win.hip: 2-D query tiles, per-(tile, level) staged value windows, global
+    fallback when a window does not fit) against the CPU oracle (fp32) and against the streaming kernels (both dtypes):
+    forward, d_loc, d_attw, d_value.  'self': queries = the levels themselves; 'cross': one query map at twice the
+    resolution of level 0; 'scattered': uniformly random locations (every finest-level window overflows -> fallback
+    path); 'ragged': map sizes that are not multiples of the tile, 5 % scattered points, a level smaller than a tile."""
+    from gedepth_amd.kernels import ms_deform_attn, msda_mode
+    shapes = {'self': ((44, 70), (22, 35), (11, 18), (6, 9)), 'cross': ((22, 35), (11, 18), (6, 9), (3, 5)),
+              'scattered': ((44, 70), (22, 35), (11, 18), (6, 9)), 'ragged': ((37, 53), (19, 27), (10, 14), (5, 7))}[case]
+    qshapes = {'self': shapes, 'cross': ((44, 70),), 'scattered': shapes, 'ragged': ((21, 45), (3, 5))}[case]
+    B = 2
+    nv = sum(h * w for h, w in shapes)
+    nq = sum(h * w for h, w in qshapes)
+    g = gen(17)
+    value = torch.randn(B, nv, 8, 64, generator=g)
+    go = torch.randn(B, nq, 512, generator=g)
+    if case == 'scattered':
+        loc = torch.rand(B, nq, 8, 4, 8, 2, generator=g) * 1.3 - 0.15
+        aw = torch.rand(B, nq, 8, 4, 8, generator=g).flatten(-2).softmax(-1).view(B, nq, 8, 4, 8)
+    else:
+        loc, aw = _coherent_locations(B, qshapes, shapes, 5, spread=0.05 if case == 'ragged' else 0.0)
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    value, go = value.to(td), go.to(td)
+
+    def run(mode, qs):
+        old = msda_mode(mode)
+        try:
+            vg = value.to(dev).requires_grad_(True)
+            lg, ag = loc.to(dev).requires_grad_(True), aw.to(dev).requires_grad_(True)
+            out = ms_deform_attn(vg, shapes, lg, ag, query_shapes=qs)
+            out.backward(go.to(dev))
+            return [t.float().cpu() for t in (out, vg.grad, lg.grad, ag.grad)]
+        finally:
+            msda_mode(old)
+    win = run(3, qshapes)
+    stream = run(0, qshapes)
+    names = ('out', 'd value', 'd loc', 'd attw')
+    # same arithmetic per (query, head): the two decompositions agree to the order of the 8-lane / 16-lane reductions
+    for a, b, n in zip(win, stream, names):
+        if dtype == 'f32':
+            close_scaled(a, b, rel=2e-5, what=f'window vs streaming: {n}')
+        else:
+            close_scaled(a, b, rel=1e-2 if n in ('out', 'd value') else 2e-5, what=f'window vs streaming (bf16): {n}')
+    if dtype == 'f32':
+        vc, lc, ac = (t.clone().requires_grad_(True) for t in (value, loc, aw))
+        ref = O.msda_core(vc, shapes, lc, ac)
+        ref.backward(go)
+        close(win[0], ref, what='out vs oracle')
+        close_scaled(win[1], vc.grad, what='d value vs oracle')
+        close_scaled(win[3], ac.grad, what='d attw vs oracle')
+        close_scaled(win[2], lc.grad, rel=2e-4, what='d loc vs oracle')
+
+
 def test_msda_large_maps_use_per_head_histograms(dev):
     """Value maps whose (heads x tiles) histogram exceeds one workgroup's LDS (native-resolution DDAD, config #4) take the
     one-head-per-workgroup counting sort; same results as the oracle, and the workspace path is really taken."""
