@@ -87,7 +87,7 @@ static inline int msda_levels(const int* spatial_hw, int L, int Nv, MsdaLevels& 
 // LDS-window kernels (msda_win.hip); query geometry = n_qseg (H, W) segments of queries in raster order
 int msda_win_supported(int B, int Nq, int nH, int L, int P, int Nv);
 int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc, const float* attw,
-                        void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, hipStream_t s);
+                        void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, bool pre, hipStream_t s);
 int msda_bwd_lw_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc,
                            const float* attw, const void* gout, float* d_loc, float* d_attw, int B, int Nv, int Nq, int nH, int L,
-                           int P, int dtype, hipStream_t s);
+                           int P, int dtype, bool pre, hipStream_t s);

@@ -716,12 +716,13 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
 }
 
 
-// Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry); the
+// Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry), bit 2 =
+// owner-lane tap arithmetic in the window kernels; the
 // streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
-static int g_msda_mode = 3;
+static int g_msda_mode = 7;
 extern "C" int ge_msda_mode(int mode) {
   const int old = g_msda_mode;
-  if (mode >= 0) g_msda_mode = mode & 3;
+  if (mode >= 0) g_msda_mode = mode & 7;
   return old;
 }
 
@@ -735,7 +736,7 @@ extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const int* 
   if (n_groups == 0) return GE_OK;
   if (dtype != GE_F32 && dtype != GE_BF16) return GE_ERR_UNSUPPORTED;
   if ((g_msda_mode & 1) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv))
-    return msda_fwd_win_launch(value, lv, query_hw, n_qseg, loc, attw, out, B, Nv, Nq, nH, L, P, dtype, ge_stream(stream));
+    return msda_fwd_win_launch(value, lv, query_hw, n_qseg, loc, attw, out, B, Nv, Nq, nH, L, P, dtype, (g_msda_mode & 4) != 0, ge_stream(stream));
   if ((n_groups + 15) / 16 > (1L << 30) || (long)Nv * nH * 64 >= (1L << 31)) return GE_ERR_UNSUPPORTED;
   const unsigned blocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
   if (dtype == GE_F32)
@@ -864,7 +865,7 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   { std::lock_guard<std::mutex> lk(g_msda_mu); if (g_msda_timing) ev = evs; }
   msda_mark(ev, 0, s);
   if ((g_msda_mode & 2) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv)) {
-    e = msda_bwd_lw_win_launch(value, lv, query_hw, n_qseg, loc, attw, d_out, d_loc, d_attw, B, Nv, Nq, nH, L, P, dtype, s);
+    e = msda_bwd_lw_win_launch(value, lv, query_hw, n_qseg, loc, attw, d_out, d_loc, d_attw, B, Nv, Nq, nH, L, P, dtype, (g_msda_mode & 4) != 0, s);
     if (e) return e;
   } else {
     const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);   // one trip per workgroup, in query order

@@ -177,7 +177,10 @@ __device__ __forceinline__ void mw_queries(const MsdaQGrid& qg, const MwJob& job
   }
 }
 
-template <typename T>
+// PRE = true: the lane that owns a sampling point also does its tap arithmetic once (window row index with the +1 column /
+// +1 row flags packed into bits 30 / 31, the four final weights) and the 8 lanes of the group fetch 5 values per point by
+// ds_bpermute, instead of every lane redoing the floor / clamp / mask arithmetic from (x, y, weight): ~35 VALU less per point.
+template <typename T, bool PRE>
 __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ value, MsdaLevels lv, MsdaQGrid qg,
                                                       const float* __restrict__ loc, const float* __restrict__ attw,
                                                       T* __restrict__ out, int B, int Nv, int Nq, int nH, int L, int P) {
@@ -205,29 +208,65 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
     if (box[3] == 0) continue;                                  // nothing in this tile samples level l (uniform)
     const int x0w = box[0], y0w = box[1], bw = box[2];
     const uint4* gsrc = (const uint4*)(vl + sub * CPL);
+    const int s16 = nh64 * (int)sizeof(T) / 16;                 // global row stride in 16-byte units
+    if constexpr (PRE) {
+      const int rstride = staged ? bw : Wl;
+      int pk[MW_QPG];
+      float w00[MW_QPG], w01[MW_QPG], w10[MW_QPG], w11[MW_QPG];
 #pragma unroll
-    for (int i = 0; i < MW_QPG; ++i) {
-#pragma unroll 1
-      for (int p = 0; p < 8; ++p) {
-        const float x = __shfl(px[i], p, G), y = __shfl(py[i], p, G), wgt = __shfl(pw[i], p, G);
-        const bool in = x > -1.5f;
-        const MwTap t = mw_tap(x, y, Wl, Hl);
+      for (int i = 0; i < MW_QPG; ++i) {                        // this lane's own point of query i
+        const bool in = px[i] > -1.5f;
+        const MwTap t = mw_tap(px[i], py[i], Wl, Hl);
         const float bx = 1.f - t.ax, by = 1.f - t.ay;
         const float wxa = (in && t.kxa) ? bx : 0.f, wxb = (in && t.kxb) ? t.ax : 0.f;
         const float wya = t.kya ? by : 0.f, wyb = t.kyb ? t.ay : 0.f;
-        uint4 r00, r01, r10, r11;
-        if (staged) {
-          // a point that samples nothing reads row 0 of the window (valid data) with zero weights
-          const int ra = in ? (t.ya - y0w) * bw - x0w : 0, rb = in ? (t.yb - y0w) * bw - x0w : 0;
-          const int xa = in ? t.xa : 0, xb = in ? t.xb : 0;
-          r00 = win[(ra + xa) * G + sub]; r01 = win[(ra + xb) * G + sub];
-          r10 = win[(rb + xa) * G + sub]; r11 = win[(rb + xb) * G + sub];
-        } else {
-          const long s16 = nh64 * (int)sizeof(T) / 16;             // row stride in 16-byte units
-          r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
-          r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
+        const int i00 = staged ? (t.ya - y0w) * bw + (t.xa - x0w) : t.ya * Wl + t.xa;
+        pk[i] = in ? (i00 | ((t.xb - t.xa) << 30) | ((t.yb - t.ya) << 31)) : 0;
+        w00[i] = wya * wxa * pw[i]; w01[i] = wya * wxb * pw[i]; w10[i] = wyb * wxa * pw[i]; w11[i] = wyb * wxb * pw[i];
+      }
+#pragma unroll
+      for (int i = 0; i < MW_QPG; ++i) {
+#pragma unroll 2
+        for (int p = 0; p < 8; ++p) {
+          const int k = __shfl(pk[i], p, G);
+          const float a = __shfl(w00[i], p, G), b = __shfl(w01[i], p, G), c = __shfl(w10[i], p, G), d = __shfl(w11[i], p, G);
+          const int i00 = k & 0x3fffffff, dx = (k >> 30) & 1;
+          const int i10 = i00 + ((k >> 31) & rstride);
+          uint4 r00, r01, r10, r11;
+          if (staged) {
+            r00 = win[i00 * G + sub]; r01 = win[(i00 + dx) * G + sub];
+            r10 = win[i10 * G + sub]; r11 = win[(i10 + dx) * G + sub];
+          } else {
+            r00 = gsrc[(long)i00 * s16]; r01 = gsrc[(long)(i00 + dx) * s16];
+            r10 = gsrc[(long)i10 * s16]; r11 = gsrc[(long)(i10 + dx) * s16];
+          }
+          MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, a, b, c, d);
         }
-        MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, wya * wxa * wgt, wya * wxb * wgt, wyb * wxa * wgt, wyb * wxb * wgt);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MW_QPG; ++i) {
+#pragma unroll 1
+        for (int p = 0; p < 8; ++p) {
+          const float x = __shfl(px[i], p, G), y = __shfl(py[i], p, G), wgt = __shfl(pw[i], p, G);
+          const bool in = x > -1.5f;
+          const MwTap t = mw_tap(x, y, Wl, Hl);
+          const float bx = 1.f - t.ax, by = 1.f - t.ay;
+          const float wxa = (in && t.kxa) ? bx : 0.f, wxb = (in && t.kxb) ? t.ax : 0.f;
+          const float wya = t.kya ? by : 0.f, wyb = t.kyb ? t.ay : 0.f;
+          uint4 r00, r01, r10, r11;
+          if (staged) {
+            // a point that samples nothing reads row 0 of the window (valid data) with zero weights
+            const int ra = in ? (t.ya - y0w) * bw - x0w : 0, rb = in ? (t.yb - y0w) * bw - x0w : 0;
+            const int xa = in ? t.xa : 0, xb = in ? t.xb : 0;
+            r00 = win[(ra + xa) * G + sub]; r01 = win[(ra + xb) * G + sub];
+            r10 = win[(rb + xa) * G + sub]; r11 = win[(rb + xb) * G + sub];
+          } else {
+            r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
+            r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
+          }
+          MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, wya * wxa * wgt, wya * wxb * wgt, wyb * wxa * wgt, wyb * wxb * wgt);
+        }
       }
     }
   }
@@ -238,7 +277,7 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
 
 // d_loc / d_attw: per point the four <gradient row, value row> dot products (raw bf16 pairs through v_dot2c), the three
 // sums (weight, d/dx, d/dy) reduce-scattered over the lane group exactly as in msda_bwd_lw_k.
-template <typename T>
+template <typename T, bool PRE>
 __global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ value, MsdaLevels lv, MsdaQGrid qg,
                                                          const float* __restrict__ loc, const float* __restrict__ attw,
                                                          const T* __restrict__ gout, float* __restrict__ d_loc,
@@ -267,13 +306,52 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ v
     const int x0w = box[0], y0w = box[1], bw = box[2];
     const lw_raw_t* gsrc = (const lw_raw_t*)(vl + sub * CPL);
     const lw_raw_t* lwin = (const lw_raw_t*)win;
+    const int s16 = nh64 * (int)sizeof(T) / 16;
+    const int rstride = staged ? bw : Wl;
+    int pk[MW_QPG];
+    if constexpr (PRE) {
+      // owner lane: window row index (26 bits) | corner masks kxa, kxb, kya, kyb (bits 26-29) | +1 column / +1 row flags (30, 31);
+      // px / py are overwritten with the fractional parts, pw stays the weight
+#pragma unroll
+      for (int i = 0; i < MW_QPG; ++i) {
+        const bool in = px[i] > -1.5f;
+        const MwTap t = mw_tap(px[i], py[i], Wl, Hl);
+        const int i00 = staged ? (t.ya - y0w) * bw + (t.xa - x0w) : t.ya * Wl + t.xa;
+        const int m = (t.kxa ? 1 : 0) | (t.kxb ? 2 : 0) | (t.kya ? 4 : 0) | (t.kyb ? 8 : 0);
+        pk[i] = in ? (i00 | (m << 26) | ((t.xb - t.xa) << 30) | ((t.yb - t.ya) << 31)) : 0;
+        px[i] = t.ax; py[i] = t.ay;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MW_QPG; ++i) {
       float part[24];
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         float sv = 0.f, sx = 0.f, sy = 0.f;
-        if (!empty) {
+        if (PRE && !empty) {
+          const int k = __shfl(pk[i], p, G);
+          const float ax = __shfl(px[i], p, G), ay = __shfl(py[i], p, G), wgt = __shfl(pw[i], p, G);
+          const float bx = 1.f - ax, by = 1.f - ay;
+          const int i00 = k & 0x03ffffff, dx = (k >> 30) & 1;
+          const int i10 = i00 + ((k >> 31) & rstride);
+          lw_raw_t r00, r01, r10, r11;
+          if (staged) {
+            r00 = lwin[i00 * G + sub]; r01 = lwin[(i00 + dx) * G + sub];
+            r10 = lwin[i10 * G + sub]; r11 = lwin[(i10 + dx) * G + sub];
+          } else {
+            r00 = gsrc[(long)i00 * s16]; r01 = gsrc[(long)(i00 + dx) * s16];
+            r10 = gsrc[(long)i10 * s16]; r11 = gsrc[(long)(i10 + dx) * s16];
+          }
+          float d00 = RowDot<T>::dot(go[i], r00), d01 = RowDot<T>::dot(go[i], r01);
+          float d10 = RowDot<T>::dot(go[i], r10), d11 = RowDot<T>::dot(go[i], r11);
+          const bool kxa = k & (1 << 26), kxb = k & (2 << 26), kya = k & (4 << 26), kyb = k & (8 << 26);
+          d00 = (kya && kxa) ? d00 : 0.f; d01 = (kya && kxb) ? d01 : 0.f;
+          d10 = (kyb && kxa) ? d10 : 0.f; d11 = (kyb && kxb) ? d11 : 0.f;
+          sv = by * bx * d00 + by * ax * d01 + ay * bx * d10 + ay * ax * d11;
+          sx = (by * (d01 - d00) + ay * (d11 - d10)) * (wgt * (float)Wl);
+          sy = (bx * (d10 - d00) + ax * (d11 - d01)) * (wgt * (float)Hl);
+        }
+        if (!PRE && !empty) {
           const float x = __shfl(px[i], p, G), y = __shfl(py[i], p, G), wgt = __shfl(pw[i], p, G);
           const bool in = x > -1.5f;
           const MwTap t = mw_tap(x, y, Wl, Hl);
@@ -285,7 +363,6 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ v
             r00 = lwin[(ra + xa) * G + sub]; r01 = lwin[(ra + xb) * G + sub];
             r10 = lwin[(rb + xa) * G + sub]; r11 = lwin[(rb + xb) * G + sub];
           } else {
-            const long s16 = nh64 * (int)sizeof(T) / 16;
             r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
             r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
           }
@@ -366,7 +443,7 @@ int msda_win_supported(int B, int Nq, int nH, int L, int P, int Nv) {
 }
 
 int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc, const float* attw,
-                        void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, hipStream_t s) {
+                        void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, bool pre, hipStream_t s) {
   MsdaQGrid qg;
   const bool f32 = dtype == GE_F32;
   int e = mw_qgrid(query_hw, n_qseg, Nq, f32 ? WinGeom<float>::TQH : WinGeom<bf16_t>::TQH, 16, qg);
@@ -375,17 +452,17 @@ int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* quer
   if (total <= 0) return GE_OK;
   if (total > (1L << 30)) return GE_ERR_UNSUPPORTED;
   const unsigned blocks = msda_grid(total, 1);
-  if (f32)
-    msda_fwd_win_k<float><<<blocks, 256, 0, s>>>((const float*)value, lv, qg, loc, attw, (float*)out, B, Nv, Nq, nH, L, P);
-  else
-    msda_fwd_win_k<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)value, lv, qg, loc, attw, (bf16_t*)out, B, Nv, Nq, nH, L, P);
+#define MW_FWD(TT, PR) msda_fwd_win_k<TT, PR><<<blocks, 256, 0, s>>>((const TT*)value, lv, qg, loc, attw, (TT*)out, B, Nv, Nq, nH, L, P)
+  if (f32) { if (pre) MW_FWD(float, true); else MW_FWD(float, false); }
+  else { if (pre) MW_FWD(bf16_t, true); else MW_FWD(bf16_t, false); }
+#undef MW_FWD
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
 
 int msda_bwd_lw_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc,
                            const float* attw, const void* gout, float* d_loc, float* d_attw, int B, int Nv, int Nq, int nH, int L,
-                           int P, int dtype, hipStream_t s) {
+                           int P, int dtype, bool pre, hipStream_t s) {
   MsdaQGrid qg;
   const bool f32 = dtype == GE_F32;
   int e = mw_qgrid(query_hw, n_qseg, Nq, f32 ? WinGeom<float>::TQH : WinGeom<bf16_t>::TQH, 16, qg);
@@ -394,10 +471,10 @@ int msda_bwd_lw_win_launch(const void* value, const MsdaLevels& lv, const int* q
   if (total <= 0) return GE_OK;
   if (total > (1L << 30)) return GE_ERR_UNSUPPORTED;
   const unsigned blocks = msda_grid(total, 1);
-  if (f32)
-    msda_bwd_lw_win_k<float><<<blocks, 256, 0, s>>>((const float*)value, lv, qg, loc, attw, (const float*)gout, d_loc, d_attw, B, Nv, Nq, nH, L, P);
-  else
-    msda_bwd_lw_win_k<bf16_t><<<blocks, 256, 0, s>>>((const bf16_t*)value, lv, qg, loc, attw, (const bf16_t*)gout, d_loc, d_attw, B, Nv, Nq, nH, L, P);
+#define MW_LW(TT, PR) msda_bwd_lw_win_k<TT, PR><<<blocks, 256, 0, s>>>((const TT*)value, lv, qg, loc, attw, (const TT*)gout, d_loc, d_attw, B, Nv, Nq, nH, L, P)
+  if (f32) { if (pre) MW_LW(float, true); else MW_LW(float, false); }
+  else { if (pre) MW_LW(bf16_t, true); else MW_LW(bf16_t, false); }
+#undef MW_LW
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

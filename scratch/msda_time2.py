@@ -46,7 +46,7 @@ for name, qshapes in (('cross', [(H // 2, W // 2)]), ('self', shapes)):
     aw = torch.rand(B, Nq, 8, 32, device=dev).softmax(-1).view(B, Nq, 8, 4, 8).requires_grad_(True)
     go = torch.randn(B, Nq, 512, device=dev).bfloat16()
     res = {}
-    for mode in (3, 0):
+    for mode in (7, 3, 0):
         msda_mode(mode)
         for it in range(4):
             if it == 1:
@@ -60,5 +60,5 @@ for name, qshapes in (('cross', [(H // 2, W // 2)]), ('self', shapes)):
         for r in kernels.PROFILER.summary() + kernels.PROFILER.msda_bwd_stages():
             print(f'{name:5s} mode {mode} {r["name"]:48s} {r["avg_us"] / 1e3:8.3f} ms')
     for i, n in enumerate(('out', 'd_loc', 'd_attw')):
-        a, b = res[3][i], res[0][i]
+        a, b = res[7][i], res[0][i]
         print(f'{name} {n}: max |win - stream| = {(a - b).abs().max().item():.3e} (scale {b.abs().max().item():.3e})')

@@ -282,15 +282,17 @@ def test_msda_window_kernels(dev, case, dtype):
             return [t.float().cpu() for t in (out, vg.grad, lg.grad, ag.grad)]
         finally:
             msda_mode(old)
-    win = run(3, qshapes)
+    win = run(7, qshapes)                                   # window kernels, owner-lane tap arithmetic (the default)
+    win_plain = run(3, qshapes)                             # window kernels, per-lane tap arithmetic
     stream = run(0, qshapes)
     names = ('out', 'd value', 'd loc', 'd attw')
-    # same arithmetic per (query, head): the two decompositions agree to the order of the 8-lane / 16-lane reductions
-    for a, b, n in zip(win, stream, names):
-        if dtype == 'f32':
-            close_scaled(a, b, rel=2e-5, what=f'window vs streaming: {n}')
-        else:
-            close_scaled(a, b, rel=1e-2 if n in ('out', 'd value') else 2e-5, what=f'window vs streaming (bf16): {n}')
+    # same arithmetic per (query, head): the decompositions agree to the order of the 8-lane / 16-lane reductions
+    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)')):
+        for a, b, n in zip(w, stream, names):
+            if dtype == 'f32':
+                close_scaled(a, b, rel=2e-5, what=f'{tag} vs streaming: {n}')
+            else:
+                close_scaled(a, b, rel=1e-2 if n in ('out', 'd value') else 2e-5, what=f'{tag} vs streaming (bf16): {n}')
     if dtype == 'f32':
         vc, lc, ac = (t.clone().requires_grad_(True) for t in (value, loc, aw))
         ref = O.msda_core(vc, shapes, lc, ac)
