@@ -165,6 +165,14 @@ def build_job(args, cfg, dev, rank, dtype):
     return step, per_gpu, optimizer
 
 
+T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress on stderr (the JSON line owns stdout)"""
+    print(f'[bench {time.perf_counter() - T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 def fence():
     if dist.is_initialized():
         dist.barrier()
@@ -209,9 +217,11 @@ def main():
     cfg.model.pretrained = None                             # random-init weights of the named architecture
     step, per_gpu, optimizer = build_job(args, cfg, dev, rank, args.dtype)
 
+    note(f'model built ({args.config}, {args.dtype}); warm-up + timed region')
     # ---- pass 1: the headline number; the per-kernel event profiler is OFF inside the timed region
     elapsed, out = timed_steps(step, args.warmup, args.steps, dev, world)
     loss = out['log_vars']['loss']
+    note(f'timed region done: {1e3 * elapsed / args.steps:.2f} ms/step; kernel-timing pass')
     # ---- pass 2: the same steps again with HIP events around every hand-written kernel (roofline object)
     prof, stages = [], []
     if not args.no_kernel_timing and args.profile_steps > 0:
@@ -260,16 +270,21 @@ def main():
 
     # ---- reference-precision (fp32, exact-fp32 attention off: library fp32 GEMM/conv + the same HIP kernels) line at N=1
     if world == 1 and args.dtype != 'fp32' and not args.no_fp32:
+        # the committed MIOpen find-db holds the bf16 problems only: with find mode on, every fp32 convolution would be
+        # timed from scratch (minutes); the fp32 line uses MIOpen's immediate-mode heuristics instead
+        torch.backends.cudnn.benchmark = False
+        note('fp32 leg')
         step32, _, opt32 = build_job(args, cfg, dev, rank, 'fp32')
         e32, o32 = timed_steps(step32, 2, args.fp32_steps, dev, world)
         if rank == 0:
             res['fp32'] = {'value': round(per_gpu * args.fp32_steps / e32, 3), 'unit': 'img/s', 'ms_per_step': round(1e3 * e32 / args.fp32_steps, 3),
                            'steps': args.fp32_steps, 'warmup': 2, 'dtype': 'fp32', 'last_loss': round(float(o32['log_vars']['loss']), 5),
-                           'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision)'}
+                           'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision; exact-fp32 window attention, MIOpen immediate mode)'}
         del step32, opt32, o32
         torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            note('cpu baseline (oracle, 1+3 train steps, 1+3 eval)')
             res['cpu_baseline'] = cpu_baseline(args.config, args.height, args.width)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():

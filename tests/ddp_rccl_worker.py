@@ -31,30 +31,41 @@ def run(active):
     ddp = FlatDDP(model, optimizer.arena, bucket_mb=8)
     assert ddp.active == active and (not active or (ddp.backend == 'nccl' and len(ddp.buckets) > 2)), (ddp.active, ddp.backend)
     batch = synthetic_batch(2, 128, 160, seed=21, device=dev, valid_fraction=0.3)
-    losses = []
-    for _ in range(2):
+    losses, grad = [], None
+    for it in range(2):
         optimizer.zero_grad()
         out = ddp.train_step(batch, optimizer)
         out['loss'].backward()
         ddp.finish()
+        if it == 0:
+            torch.cuda.synchronize()
+            grad = optimizer.arena.flat_grad.detach().clone()        # after the (averaging) all-reduce of world size 1
         optimizer.step()
         losses.append(float(out['log_vars']['loss']))
     torch.cuda.synchronize()
-    return losses, optimizer.arena.flat_param.detach().clone()
+    return losses, grad
 
 
 def main():
     from gedepth_amd.mmrt.ddp import init_dist
     rank, local, world = init_dist('nccl')
     assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1
-    la, pa = run(True)
-    lb, pb = run(False)
-    # not bit-for-bit: the deformable-attention scatter combines chunks of a value tile with fp32 atomics (run-to-run order)
-    assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(la, lb)), (la, lb)
-    assert (pa - pb).abs().max().item() <= 2e-6, (pa - pb).abs().max().item()
+    la, ga = run(True)
+    lb, gb = run(False)
+    # not bit-for-bit: the deformable-attention scatter combines chunks of a value tile with fp32 atomics (run-to-run
+    # order), and AdamW turns a sign flip of a noise-level gradient into a full +-lr step — so the exchanged GRADIENT of the
+    # first step and the losses are compared, not the parameters
+    rel = ((ga - gb).double().norm() / gb.double().norm()).item()
+    assert rel <= 1e-5, rel
+    assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]) and abs(la[1] - lb[1]) <= 1e-3 * abs(lb[1]), (la, lb)
     dist.destroy_process_group()
-    print('RCCL_DDP_OK', la)
+    print('RCCL_DDP_OK', la, rel)
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except BaseException:
+        import traceback
+        print('RCCL_DDP_FAILED\n' + traceback.format_exc(), flush=True)
+        raise

@@ -268,8 +268,9 @@ def test_ddad_per_camera_height_vs_oracle(dev):
     set_exact(model)
     batch = synthetic_batch(2, 64, 96, seed=11, valid_fraction=0.3)
     heights = torch.tensor([1.56, 1.53])
-    losses, _ = O.forward_train(batch['img'], batch['depth_gt'], batch['pe_k_gt'], P, dict(O.SWIN_L, adaptive=True), train_bn=True,
-                                height=heights)
+    cfg_ddad = dict(O.SWIN_L, adaptive=True, depth_scale=250.0)     # configs/depthformer/depthformer_v_ddad.py: model.depth_scale
+    assert model.depth_scale == 250
+    losses, _ = O.forward_train(batch['img'], batch['depth_gt'], batch['pe_k_gt'], P, cfg_ddad, train_bn=True, height=heights)
     _, ref = O.parse_losses(losses)
     gb = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     out = model.train_step(dict(gb, height=heights.to(dev)), None)
@@ -288,4 +289,4 @@ def test_rccl_gradient_exchange_single_rank(dev):
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_rccl_worker.py')], env=env, capture_output=True, text=True,
                        timeout=600)
-    assert r.returncode == 0 and 'RCCL_DDP_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and 'RCCL_DDP_OK' in r.stdout, (r.stdout[-3000:], r.stderr[-6000:])
