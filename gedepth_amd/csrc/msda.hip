@@ -44,7 +44,20 @@ __device__ __forceinline__ float group16_sum(float v) {
   return v;
 }
 
-template <typename T>
+// HM (head-major work order): the work index runs (image, head, query) instead of (image, query, head), so that everything
+// an XCD has in flight samples ONE head of ONE image — 4.2 MB of value rows at the KITTI shape, which its 4 MB L2 mostly
+// holds — instead of all 8 heads (33.5 MB).  For query sets without spatial coherence (the cross-attention at
+// initialisation: reference points = sigmoid(Linear(sine embedding)), a high-frequency function of the position) the
+// kernel is bound by what misses L2, not by the gather instruction rate.
+__device__ __forceinline__ long msda_group(long v, int Nq, int nH, bool hm) {
+  if (!hm) return v;
+  const long bh = v / Nq;
+  const long q = v - bh * Nq;
+  const long b = bh / nH;
+  return (b * Nq + q) * nH + (bh - b * nH);
+}
+
+template <typename T, bool HM>
 __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
                                                   const float* __restrict__ attw, T* __restrict__ out,
                                                   long n_groups, int Nv, int Nq, int nH, int L, int P) {
@@ -53,7 +66,8 @@ __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, M
   const int nh64 = nH * 64;                                 // 32-bit element offsets inside one image (launcher: Nv * nH * 64 < 2^31)
   const long grp0 = msda_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x / G) + (threadIdx.x / G);
   const long gstride = (long)gridDim.x * (blockDim.x / G);
-  for (long grp = grp0; grp < n_groups; grp += gstride) {   // grp = (b*Nq + q)*nH + head (one trip: the grid covers all)
+  for (long vgrp = grp0; vgrp < n_groups; vgrp += gstride) {   // grp = (b*Nq + q)*nH + head (one trip: the grid covers all)
+    const long grp = msda_group(vgrp, Nq, nH, HM);
     const int head = (int)(grp % nH);
     const long bq = grp / nH;
     const int b = (int)(bq / Nq);
@@ -225,7 +239,7 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
 // d_loc / d_attw only (the binned path computes d_value separately): same 16-lane-group decomposition as the forward
 // kernel (4 channels per lane, one 16-byte / 8-byte load per tap and lane, four (query, head) pairs per wave), the three
 // per-point sums reduced over the group with a 4-step butterfly.
-template <typename T>
+template <typename T, bool HM>
 __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
                                                      const float* __restrict__ attw, const T* __restrict__ gout,
                                                      float* __restrict__ d_loc, float* __restrict__ d_attw, long n_groups,
@@ -239,9 +253,9 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
   const long iters = (n_groups + gstride - 1) / gstride;          // wave-uniform trip count: the shuffles need all lanes
   const int LP = L * P;
   for (long it = 0; it < iters; ++it) {
-    const long grp = grp0 + it * gstride;
-    const bool live = grp < n_groups;
-    const long g_ = live ? grp : 0;
+    const long vgrp = grp0 + it * gstride;
+    const bool live = vgrp < n_groups;
+    const long g_ = live ? msda_group(vgrp, Nq, nH, HM) : 0;
     const int head = (int)(g_ % nH);
     const int b = (int)((g_ / nH) / Nq);
     const float* lp = loc + g_ * (long)(LP * 2);
@@ -717,12 +731,12 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
 
 
 // Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry), bit 2 =
-// owner-lane tap arithmetic in the window kernels; the
+// owner-lane tap arithmetic in the window kernels, bit 3 = head-major work order in the streaming kernels; the
 // streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
 static int g_msda_mode = 7;
 extern "C" int ge_msda_mode(int mode) {
   const int old = g_msda_mode;
-  if (mode >= 0) g_msda_mode = mode & 7;
+  if (mode >= 0) g_msda_mode = mode & 15;
   return old;
 }
 
@@ -739,12 +753,11 @@ extern "C" int ge_msda_fwd(const void* value, const int* spatial_hw, const int* 
     return msda_fwd_win_launch(value, lv, query_hw, n_qseg, loc, attw, out, B, Nv, Nq, nH, L, P, dtype, (g_msda_mode & 4) != 0, ge_stream(stream));
   if ((n_groups + 15) / 16 > (1L << 30) || (long)Nv * nH * 64 >= (1L << 31)) return GE_ERR_UNSUPPORTED;
   const unsigned blocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
-  if (dtype == GE_F32)
-    msda_fwd_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)value, lv, loc, attw, (float*)out, n_groups, Nv, Nq, nH, L, P);
-  else if (dtype == GE_BF16)
-    msda_fwd_k<bf16_t><<<blocks, 256, 0, ge_stream(stream)>>>((const bf16_t*)value, lv, loc, attw, (bf16_t*)out, n_groups, Nv, Nq, nH, L, P);
-  else
-    return GE_ERR_UNSUPPORTED;
+  const bool hm = (g_msda_mode & 8) != 0;
+#define MSDA_FWD(TT, HM_) msda_fwd_k<TT, HM_><<<blocks, 256, 0, ge_stream(stream)>>>((const TT*)value, lv, loc, attw, (TT*)out, n_groups, Nv, Nq, nH, L, P)
+  if (dtype == GE_F32) { if (hm) MSDA_FWD(float, true); else MSDA_FWD(float, false); }
+  else { if (hm) MSDA_FWD(bf16_t, true); else MSDA_FWD(bf16_t, false); }
+#undef MSDA_FWD
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
@@ -869,10 +882,11 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
     if (e) return e;
   } else {
     const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);   // one trip per workgroup, in query order
-    if (dtype == GE_F32)
-      msda_bwd_lw_k<float><<<lblocks, 256, 0, s>>>((const float*)value, lv, loc, attw, (const float*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
-    else
-      msda_bwd_lw_k<bf16_t><<<lblocks, 256, 0, s>>>((const bf16_t*)value, lv, loc, attw, (const bf16_t*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P);
+    const bool hm = (g_msda_mode & 8) != 0;
+#define MSDA_LW(TT, HM_) msda_bwd_lw_k<TT, HM_><<<lblocks, 256, 0, s>>>((const TT*)value, lv, loc, attw, (const TT*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P)
+    if (dtype == GE_F32) { if (hm) MSDA_LW(float, true); else MSDA_LW(float, false); }
+    else { if (hm) MSDA_LW(bf16_t, true); else MSDA_LW(bf16_t, false); }
+#undef MSDA_LW
   }
   GE_LAUNCH_CHECK();
   msda_mark(ev, 1, s);

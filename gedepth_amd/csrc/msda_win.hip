@@ -61,8 +61,8 @@ __device__ __forceinline__ int mw_wave_max(int v) {
   return v;
 }
 
-// Workgroup -> (image, head, tile).  XCD x (= blockIdx % 8) works on a contiguous eighth of the (image, tile, head) range, so
-// the tiles that share value rows meet in one L2.
+// Workgroup -> (image, head, tile).  XCD x (= blockIdx % 8) works on a contiguous eighth of the (image, head, tile) range: what
+// it has in flight samples one head of one image (4.2 MB of value rows at the KITTI shape ~ its 4 MB L2).
 struct MwJob { int b, head, seg, ty, tx; bool live; };
 __device__ __forceinline__ MwJob mw_job(const MsdaQGrid& qg, int nH, int B) {
   MwJob j;
@@ -71,10 +71,10 @@ __device__ __forceinline__ MwJob mw_job(const MsdaQGrid& qg, int nH, int B) {
   const long total = (long)B * ntiles * nH;
   j.live = idx < total;
   const long i = j.live ? idx : 0;
-  j.head = (int)(i % nH);
-  const long bt = i / nH;
-  const int tile = (int)(bt % ntiles);
-  j.b = (int)(bt / ntiles);
+  const int tile = (int)(i % ntiles);                         // (image, head, tile): an XCD's resident workgroups share one head
+  const long bh = i / ntiles;
+  j.head = (int)(bh % nH);
+  j.b = (int)(bh / nH);
   int s = 0;
 #pragma unroll
   for (int k = 1; k < MSDA_MAX_L; ++k) s += (k < qg.nseg && tile >= qg.tile_first[k]) ? 1 : 0;

