@@ -733,7 +733,7 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
 // Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry), bit 2 =
 // owner-lane tap arithmetic in the window kernels, bit 3 = head-major work order in the streaming kernels; the
 // streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
-static int g_msda_mode = 7;
+static int g_msda_mode = 13;       // window forward + owner-lane taps + head-major streaming d_loc/d_attw (measured best)
 extern "C" int ge_msda_mode(int mode) {
   const int old = g_msda_mode;
   if (mode >= 0) g_msda_mode = mode & 15;
@@ -791,7 +791,8 @@ extern "C" int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, in
 // the duration of ONE kernel, and HIP events recorded by the caller can only bracket the whole entry point).  Off by
 // default; when off the entry point records nothing and never synchronises.
 #define MSDA_NSTAGE 5
-static const char* const kMsdaStage[MSDA_NSTAGE] = {"msda_bwd_lw(_win)_k", "msda_hist_k<false>", "msda_scan_k+msda_segscan_k",
+static bool g_msda_lw_win_used = false;
+static const char* const kMsdaStage[MSDA_NSTAGE] = {"msda_bwd_lw_k", "msda_hist_k<false>", "msda_scan_k+msda_segscan_k",
                                                     "msda_hist_k<true>", "msda_drain_k"};
 struct MsdaStageRec { int stage; hipEvent_t a, b; };
 static std::mutex g_msda_mu;
@@ -837,7 +838,8 @@ extern "C" int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launch
   msda_flush_locked();
   *total_ms = g_msda_ms[stage];
   *launches = g_msda_n[stage];
-  if (name && name_cap > 0) { strncpy(name, kMsdaStage[stage], (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+  const char* nm = (stage == 0 && g_msda_lw_win_used) ? "msda_bwd_lw_win_k" : kMsdaStage[stage];
+  if (name && name_cap > 0) { strncpy(name, nm, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
   return GE_OK;
 }
 
@@ -880,9 +882,11 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   if ((g_msda_mode & 2) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv)) {
     e = msda_bwd_lw_win_launch(value, lv, query_hw, n_qseg, loc, attw, d_out, d_loc, d_attw, B, Nv, Nq, nH, L, P, dtype, (g_msda_mode & 4) != 0, s);
     if (e) return e;
+    g_msda_lw_win_used = true;
   } else {
     const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);   // one trip per workgroup, in query order
     const bool hm = (g_msda_mode & 8) != 0;
+    g_msda_lw_win_used = false;
 #define MSDA_LW(TT, HM_) msda_bwd_lw_k<TT, HM_><<<lblocks, 256, 0, s>>>((const TT*)value, lv, loc, attw, (const TT*)d_out, d_loc, d_attw, n_groups, Nv, Nq, nH, L, P)
     if (dtype == GE_F32) { if (hm) MSDA_LW(float, true); else MSDA_LW(float, false); }
     else { if (hm) MSDA_LW(bf16_t, true); else MSDA_LW(bf16_t, false); }

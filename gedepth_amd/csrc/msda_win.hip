@@ -138,15 +138,18 @@ __device__ __forceinline__ bool mw_stage(const T* __restrict__ vl, int Wl, int H
 
 template <typename T> struct MwAcc;
 template <> struct MwAcc<bf16_t> {
+  // four chained FMAs per channel straight into the accumulator (no separate sum + add: the kernel is VALU-bound)
   static __device__ __forceinline__ void fma4(float* acc, const uint4& a, const uint4& b, const uint4& c, const uint4& d,
                                               float w00, float w01, float w10, float w11) {
     const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w}, rc[4] = {c.x, c.y, c.z, c.w}, rd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      acc[2 * i] += w00 * __uint_as_float(ra[i] << 16) + w01 * __uint_as_float(rb[i] << 16) + w10 * __uint_as_float(rc[i] << 16) +
-                    w11 * __uint_as_float(rd[i] << 16);
-      acc[2 * i + 1] += w00 * __uint_as_float(ra[i] & 0xffff0000u) + w01 * __uint_as_float(rb[i] & 0xffff0000u) +
-                        w10 * __uint_as_float(rc[i] & 0xffff0000u) + w11 * __uint_as_float(rd[i] & 0xffff0000u);
+      float lo = acc[2 * i], hi = acc[2 * i + 1];
+      lo = fmaf(w00, __uint_as_float(ra[i] << 16), lo); hi = fmaf(w00, __uint_as_float(ra[i] & 0xffff0000u), hi);
+      lo = fmaf(w01, __uint_as_float(rb[i] << 16), lo); hi = fmaf(w01, __uint_as_float(rb[i] & 0xffff0000u), hi);
+      lo = fmaf(w10, __uint_as_float(rc[i] << 16), lo); hi = fmaf(w10, __uint_as_float(rc[i] & 0xffff0000u), hi);
+      lo = fmaf(w11, __uint_as_float(rd[i] << 16), lo); hi = fmaf(w11, __uint_as_float(rd[i] & 0xffff0000u), hi);
+      acc[2 * i] = lo; acc[2 * i + 1] = hi;
     }
   }
 };
@@ -155,8 +158,12 @@ template <> struct MwAcc<float> {
                                               float w00, float w01, float w10, float w11) {
     const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w}, rc[4] = {c.x, c.y, c.z, c.w}, rd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[i] += w00 * __uint_as_float(ra[i]) + w01 * __uint_as_float(rb[i]) + w10 * __uint_as_float(rc[i]) + w11 * __uint_as_float(rd[i]);
+    for (int i = 0; i < 4; ++i) {
+      float v = acc[i];
+      v = fmaf(w00, __uint_as_float(ra[i]), v); v = fmaf(w01, __uint_as_float(rb[i]), v);
+      v = fmaf(w10, __uint_as_float(rc[i]), v); v = fmaf(w11, __uint_as_float(rd[i]), v);
+      acc[i] = v;
+    }
   }
 };
 

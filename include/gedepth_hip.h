@@ -80,7 +80,8 @@ int ge_window_attn_bwd(const void* qkv, const float* qkv_bias, const float* bias
 int ge_msda_fwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
                 const float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 /* Kernel selection knob (A/B timing, tests): bit 0 = window forward, bit 1 = window d_loc/d_attw, bit 2 = owner-lane tap
- * arithmetic inside the window kernels; mode < 0 only queries.  Returns the previous mode (default 7). */
+ * arithmetic inside the window kernels, bit 3 = head-major work order of the streaming kernels; mode < 0 only queries.
+ * Returns the previous mode (default 13: window forward, streaming head-major d_loc/d_attw). */
 int ge_msda_mode(int mode);
 
 /* Backward.  d_value (B,Nv,nH,64) is ALWAYS f32 and must be zero-filled by the caller; d_loc / d_attw are fully

@@ -35,7 +35,7 @@ def oracle(dtype):
             if not k.endswith(('running_mean', 'running_var')):
                 v.requires_grad_(True)
         P['neck.' + k] = v
-    xs = [f.to(dtype).requires_grad_(True) for f in feats]
+    xs = [f.detach().clone().to(dtype).requires_grad_(True) for f in feats]
     outs = O.hahi_neck(xs, P, train_bn=True)
     sum((o * gg.to(dtype)).sum() for o, gg in zip(outs, G)).backward()
     return outs, xs, P
@@ -44,7 +44,7 @@ def oracle(dtype):
 o64, x64, P64 = oracle(torch.float64)
 o32, x32, P32 = oracle(torch.float32)
 m = m.to(dev).train()
-xg = [f.to(dev).requires_grad_(True) for f in feats]
+xg = [f.detach().clone().to(dev).requires_grad_(True) for f in feats]
 og = m(xg)
 sum((o * gg.to(dev)).sum() for o, gg in zip(og, G)).backward()
 for i in range(5):

@@ -46,7 +46,7 @@ for name, qshapes in (('cross', [(H // 2, W // 2)]), ('self', shapes)):
     aw = torch.rand(B, Nq, 8, 32, device=dev).softmax(-1).view(B, Nq, 8, 4, 8).requires_grad_(True)
     go = torch.randn(B, Nq, 512, device=dev).bfloat16()
     res = {}
-    for mode in (7, 8, 0):
+    for mode in (7, 13, 8, 0):
         msda_mode(mode)
         for it in range(4):
             if it == 1:

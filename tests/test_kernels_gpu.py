@@ -282,13 +282,14 @@ def test_msda_window_kernels(dev, case, dtype):
             return [t.float().cpu() for t in (out, vg.grad, lg.grad, ag.grad)]
         finally:
             msda_mode(old)
-    win = run(7, qshapes)                                   # window kernels, owner-lane tap arithmetic (the default)
+    win = run(7, qshapes)                                   # window kernels (forward + d_loc/d_attw), owner-lane tap arithmetic
     win_plain = run(3, qshapes)                             # window kernels, per-lane tap arithmetic
     stream = run(0, qshapes)
     stream_hm = run(8, qshapes)                             # streaming kernels, head-major work order
+    default = run(13, qshapes)                              # the default mix: window forward, streaming head-major backward
     names = ('out', 'd value', 'd loc', 'd attw')
     # same arithmetic per (query, head): the decompositions agree to the order of the 8-lane / 16-lane reductions
-    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major')):
+    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major'), (default, 'default mode 13')):
         for a, b, n in zip(w, stream, names):
             if dtype == 'f32':
                 close_scaled(a, b, rel=2e-5, what=f'{tag} vs streaming: {n}')
