@@ -156,7 +156,7 @@ def backbone(img, P, cfg, train_bn=False, prefix='backbone'):
     outs = []
     x3 = img[:, 0:3]
     stem = F.conv2d(x3, P[prefix + '.conv1.weight'], None, stride=2, padding=3)
-    stem = F.relu(batch_norm(stem, P, prefix + '.bn1', train_bn))
+    stem = relu(batch_norm(stem, P, prefix + '.bn1', train_bn), site=prefix + '.bn1')
     outs.append(stem)
     x = img[:, 0:4]
     # PatchEmbedSwin.forward, models/utils/embed.py:282-302
@@ -198,6 +198,105 @@ def sine_positional_encoding(B, H, W, num_feats=256, temperature=10000, dtype=to
     return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2).to(dtype)
 
 
+# Bilinear sampling is continuous in the sampling location but its DERIVATIVE is not: at an integer pixel coordinate the
+# left and right slopes differ.  A location that lands within rounding of such a kink gets one slope or the other depending
+# on the last bits of the GEMM that produced its offset — in any fp32 implementation, the reference included — and that
+# one choice moves the gradient of everything upstream by ~1e-3 (tests/f64ref.py measures it).  KINK_NUDGE = (tau_px, sign)
+# resolves every location within tau_px pixels of a kink to one side; the spread between sign = +1 and -1 in float64 is
+# the part of the gradient that the algorithm itself leaves undefined.  Test instrumentation only; None = off.
+# The same holds for ReLU / LeakyReLU: an element whose pre-activation is within rounding of zero passes its gradient or
+# not depending on the last bits (one flipped element of the 2 x 1536 x 2 x 3 top-level map moves every stage-3 gradient of
+# the 64 x 96 fixture by 4e-3).  KINK_NUDGE = (tau_px, tau_act, sign) also pushes pre-activations within tau_act of zero to
+# one side.
+KINK_NUDGE = None
+KINK_COUNT = [0, 0, 0, 0]    # [ambiguous sampling coordinates, coordinates seen, ambiguous activations, activations seen]
+
+
+# KINK_FORCE = dict(act={site: bool mask}, floors=[int tensor per msda_core call, in call order]) makes this oracle take
+# the SAME side as another implementation at every kink: activations use the given pass / block mask instead of the sign of
+# their own pre-activation, sampling locations are moved (by less than FORCE_MAX_SHIFT pixels, asserted) into the given
+# integer cell.  Two implementations that agree to rounding then agree on gradients to rounding as well — which is what
+# tests/test_model_gpu.py checks for the HIP path.  Test instrumentation only; None = off.
+KINK_FORCE = None
+FORCE_MAX_SHIFT = 1e-3
+FORCE_STATS = dict(act_flipped=0, act_seen=0, floor_flipped=0, floor_seen=0, max_shift_px=0.0, max_flipped_preact=0.0)
+
+
+KINK_RECORD = None            # dict(act={}, floors=[]): filled with THIS evaluation's decisions (same layout as KINK_FORCE)
+
+
+def _forced_act(x, site, slope):
+    """relu / leaky_relu with the pass mask of KINK_FORCE['act'][site] (None: not forced)."""
+    if KINK_RECORD is not None and site is not None:
+        KINK_RECORD['act'][site] = x.detach() > 0
+    if KINK_FORCE is None or site is None or site not in KINK_FORCE.get('act', {}):
+        return None
+    mask = KINK_FORCE['act'][site].to(torch.bool)
+    assert mask.shape == x.shape, (site, mask.shape, x.shape)
+    own = x.detach() > 0
+    flipped = own != mask
+    FORCE_STATS['act_flipped'] += int(flipped.sum())
+    FORCE_STATS['act_seen'] += flipped.numel()
+    if flipped.any():
+        FORCE_STATS['max_flipped_preact'] = max(FORCE_STATS['max_flipped_preact'], float(x.detach().abs()[flipped].max()))
+    return x * torch.where(mask, torch.ones((), dtype=x.dtype), torch.full((), float(slope), dtype=x.dtype))
+
+
+def _act_nudge(x):
+    if KINK_NUDGE is None:
+        return x
+    tau, sign = KINK_NUDGE[1], KINK_NUDGE[2]
+    near = x.detach().abs() < tau
+    KINK_COUNT[2] += int(near.sum())
+    KINK_COUNT[3] += near.numel()
+    return x + near.to(x.dtype) * (sign * tau)
+
+
+def relu(x, site=None):
+    forced = _forced_act(x, site, 0.0)
+    return forced if forced is not None else F.relu(_act_nudge(x))
+
+
+def leaky_relu(x, slope=0.01, site=None):
+    forced = _forced_act(x, site, slope)
+    return forced if forced is not None else F.leaky_relu(_act_nudge(x), slope)
+
+
+def _nudge_off_kinks(loc, spatial_shapes, tau_px, _tau_act, sign):
+    wh = torch.tensor([[float(w), float(h)] for h, w in spatial_shapes], dtype=loc.dtype)     # (L, 2) = (W_l, H_l)
+    wh = wh.view(1, 1, 1, len(spatial_shapes), 1, 2)
+    px = loc.detach() * wh - 0.5
+    near = (px - torch.round(px)).abs() < tau_px
+    KINK_COUNT[0] += int(near.sum())
+    KINK_COUNT[1] += near.numel()
+    return loc + near.to(loc.dtype) * (sign * tau_px) / wh
+
+
+def sampling_cells(loc, spatial_shapes):
+    """Integer cell floor(loc * (W_l, H_l) - 0.5) of every sampling coordinate: the bilinear kink decision."""
+    wh = torch.tensor([[float(w), float(h)] for h, w in spatial_shapes], dtype=loc.dtype, device=loc.device)
+    return torch.floor(loc * wh.view(1, 1, 1, len(spatial_shapes), 1, 2) - 0.5).to(torch.int32)
+
+
+def _force_floors(loc, spatial_shapes, cells):
+    """Move every sampling coordinate whose integer cell differs from ``cells`` just inside that cell."""
+    wh = torch.tensor([[float(w), float(h)] for h, w in spatial_shapes], dtype=loc.dtype).view(1, 1, 1, len(spatial_shapes), 1, 2)
+    px = loc.detach() * wh - 0.5
+    own = torch.floor(px)
+    cells = cells.to(loc.dtype)
+    assert cells.shape == px.shape, (cells.shape, px.shape)
+    mism = own != cells
+    FORCE_STATS['floor_flipped'] += int(mism.sum())
+    FORCE_STATS['floor_seen'] += mism.numel()
+    if not mism.any():
+        return loc
+    target = torch.where(cells < own, cells + (1.0 - 1e-12), cells)       # the near edge of the other cell
+    shift = torch.where(mism, target - px, torch.zeros_like(px))
+    FORCE_STATS['max_shift_px'] = max(FORCE_STATS['max_shift_px'], float(shift.abs().max()))
+    assert float(shift.abs().max()) <= FORCE_MAX_SHIFT, f'sampling cell differs by {float(shift.abs().max())} px: not a rounding-level kink'
+    return loc + shift / wh
+
+
 def msda_core(value, spatial_shapes, sampling_locations, attention_weights):
     """mmcv 1.3.13 ``multi_scale_deformable_attn_pytorch`` (not vendored; reference call sites
     necks/hahi.py:16,279-289,316-325).  value (B,Nv,nH,d); sampling_locations (B,Nq,nH,L,P,2) in
@@ -206,6 +305,12 @@ def msda_core(value, spatial_shapes, sampling_locations, attention_weights):
     bs, _, num_heads, dims = value.shape
     _, num_queries, _, num_levels, num_points, _ = sampling_locations.shape
     value_list = value.split([int(h) * int(w) for h, w in spatial_shapes], dim=1)
+    if KINK_NUDGE is not None:
+        sampling_locations = _nudge_off_kinks(sampling_locations, spatial_shapes, *KINK_NUDGE)
+    if KINK_RECORD is not None:
+        KINK_RECORD['floors'].append(sampling_cells(sampling_locations.detach(), spatial_shapes))
+    if KINK_FORCE is not None and KINK_FORCE.get('floors'):
+        sampling_locations = _force_floors(sampling_locations, spatial_shapes, KINK_FORCE['floors'].pop(0))
     grids = 2 * sampling_locations - 1
     sampled = []
     for lvl, (h, w) in enumerate(spatial_shapes):
@@ -249,9 +354,9 @@ def conv_module(x, P, prefix, train_bn, padding=0, norm=True, act='relu'):
     if norm:
         x = batch_norm(x, P, prefix + '.bn', train_bn)
     if act == 'relu':
-        x = F.relu(x)
+        x = relu(x, site=prefix)
     elif act == 'leaky':
-        x = F.leaky_relu(x, 0.01)
+        x = leaky_relu(x, 0.01, site=prefix)
     return x
 
 
@@ -361,14 +466,14 @@ def densedepth_head(inputs, P, prefix='decode_head'):
         up = F.interpolate(x, size=[skip.size(2), skip.size(3)], mode='bilinear', align_corners=True)
         x = torch.cat([up, skip], 1)
         for c in ('convA', 'convB'):
-            x = F.leaky_relu(F.conv2d(x, P[f'{prefix}.conv_list.{i}.{c}.conv.weight'],
-                                      P[f'{prefix}.conv_list.{i}.{c}.conv.bias'], padding=1), 0.01)
+            x = leaky_relu(F.conv2d(x, P[f'{prefix}.conv_list.{i}.{c}.conv.weight'],
+                                    P[f'{prefix}.conv_list.{i}.{c}.conv.bias'], padding=1), 0.01, site=f'{prefix}.conv_list.{i}.{c}')
     return x
 
 
 def depth_pred(feat, pe, y, P, prefix='decode_head', min_depth=1e-3):
     """DepthBaseDecodeHead.depth_pred, decode_heads/decode_head.py:489-508."""
-    d = F.relu(F.conv2d(feat, P[prefix + '.conv_depth.weight'], P[prefix + '.conv_depth.bias'], padding=1))
+    d = relu(F.conv2d(feat, P[prefix + '.conv_depth.weight'], P[prefix + '.conv_depth.bias'], padding=1), site=prefix + '.conv_depth')
     if pe is None:
         return d + min_depth
     pe = F.interpolate(pe, size=d.shape[2:], mode='bilinear', align_corners=True)

@@ -30,7 +30,9 @@ def l2rel(a, ref):
     return ((a - ref).norm() / (ref.norm() + 1e-300)).item()
 
 
-def run(tag, dtype=torch.float64, salt='e2e'):
+def run(tag, dtype=torch.float64, salt='e2e', kink=None, force=None, record=False):
+    """kink = (tau_px, tau_act, sign): resolve sampling locations within tau_px pixels of a bilinear kink and pre-activations
+    within tau_act of zero to one side (oracle.KINK_NUDGE)."""
     g = np.load(os.path.join(GOLDEN, tag + '.npz'), allow_pickle=False)
     spec = json.loads(str(g['spec']))
     P32 = fill_state_dict([(k, s) for k, s in spec], salt)
@@ -46,7 +48,19 @@ def run(tag, dtype=torch.float64, salt='e2e'):
     img = torch.from_numpy(g['img']).to(dtype)
     gt = torch.from_numpy(g['depth_gt']).to(dtype)
     kgt = torch.from_numpy(g['pe_k_gt'])
-    losses, _ = O.forward_train(img, gt, kgt, P, arch, train_bn=True)
+    O.KINK_NUDGE, O.KINK_COUNT[:] = kink, [0, 0, 0, 0]
+    # force = dict(act={site: mask}, floors=[cells per msda call]): take another implementation's side at every kink
+    O.KINK_FORCE = None if force is None else dict(act=dict(force.get('act', {})), floors=list(force.get('floors', [])))
+    for k in O.FORCE_STATS:
+        O.FORCE_STATS[k] = 0 if k.endswith(('flipped', 'seen')) else 0.0
+    O.KINK_RECORD = dict(act={}, floors=[]) if record else None
+    try:
+        losses, _ = O.forward_train(img, gt, kgt, P, arch, train_bn=True)
+    finally:
+        O.KINK_NUDGE = None
+        O.KINK_FORCE = None
+        decisions, O.KINK_RECORD = O.KINK_RECORD, None
+    kink_count = tuple(O.KINK_COUNT)
     loss, _ = O.parse_losses(losses)
     log_vars = {k: v.item() for k, v in losses.items()}
     log_vars['loss'] = loss.item()
@@ -54,4 +68,13 @@ def run(tag, dtype=torch.float64, salt='e2e'):
     with torch.no_grad():
         depth_eval = O.encode_decode(img, {k: v.detach() for k, v in P.items()}, arch)
     grads = {k: v.grad for k, v in P.items() if v.is_floating_point() and v.requires_grad}
-    return dict(log_vars=log_vars, depth_eval=depth_eval, grads=grads, fixture=g)
+    return dict(log_vars=log_vars, depth_eval=depth_eval, grads=grads, fixture=g, kink_count=kink_count, force_stats=dict(O.FORCE_STATS), decisions=decisions)
+
+
+def kink_spread(tag, tau_px=1e-4, tau_act=2e-5):
+    """Per tensor, how far apart two float64 evaluations are that only differ in the side taken at gradient kinks within
+    fp32 rounding reach (bilinear sampling coordinates within tau_px pixels of an integer, ReLU / LeakyReLU pre-activations
+    within tau_act of zero): the part of the gradient the algorithm leaves undefined for any fp32 implementation."""
+    up, down = run(tag, kink=(tau_px, tau_act, +1.0)), run(tag, kink=(tau_px, tau_act, -1.0))
+    spread = {k: l2rel(sample(up['grads'][k]), sample(down['grads'][k])) for k in up['grads']}
+    return spread, up['kink_count']

@@ -59,6 +59,39 @@ def _log_parity(tag, record):
         pass
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _capture_kink_decisions(model):
+    """Record which side the HIP forward takes at every gradient kink, in the layout oracle.KINK_FORCE expects: the pass
+    mask of every ConvModule activation / the stem / conv_depth's ReLU (``output > 0``; ReLU and LeakyReLU keep the sign),
+    and the integer sampling cell of every deformable-attention tap (from the fp32 locations the kernels consume)."""
+    from gedepth_amd.depth.models.necks import hahi
+    from gedepth_amd.mmrt.bricks import ConvModule
+    dec = dict(act={}, floors=[])
+    handles = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, ConvModule) or name == 'decode_head.conv_depth':
+            handles.append(mod.register_forward_hook(lambda m, i, o, name=name: dec['act'].__setitem__(name, (o.detach() > 0).cpu())))
+    bb = model.backbone
+    stem = bb.conv_stem
+    bb.conv_stem = lambda x: (lambda y: (dec['act'].__setitem__('backbone.bn1', (y.detach() > 0).cpu()), y)[1])(stem(x))
+    orig = hahi.ms_deform_attn
+
+    def spy(value, shapes, loc, aw, query_shapes=None):
+        dec['floors'].append(O.sampling_cells(loc.detach().float().cpu(), shapes))
+        return orig(value, shapes, loc, aw, query_shapes)
+    hahi.ms_deform_attn = spy
+    try:
+        yield dec
+    finally:
+        hahi.ms_deform_attn = orig
+        bb.conv_stem = stem
+        for h in handles:
+            h.remove()
+
+
 @pytest.mark.parametrize('cfg_name,tag,adaptive', [('depthformer_swint_v.py', 'e2e_T_V', False),
                                                    ('depthformer_swint_a.py', 'e2e_T_A', True),
                                                    ('depthformer_a.py', 'e2e_L_A', True)])
@@ -89,7 +122,8 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
     assert rec['depth_hip_vs_f64'] <= max(1e-4, 1.5 * rec['depth_fixture_vs_f64']), rec
     model.train()
     kw = dict(pe_k_gt=kgt) if adaptive else {}
-    out = model.train_step(dict(img=img, img_metas=metas, depth_gt=gt, **kw), None)
+    with _capture_kink_decisions(model) as decisions:
+        out = model.train_step(dict(img=img, img_metas=metas, depth_gt=gt, **kw), None)
     names = json.loads(str(g['loss_names']))
     for n, v in zip(names, g['loss_values']):
         assert abs(out['log_vars'][n] - v) <= 1e-5 * abs(v) + 1e-6, (n, out['log_vars'][n], v)
@@ -97,34 +131,40 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
     out['loss'].backward()
     params = dict(model.named_parameters())
     assert all(p.grad is not None for p in params.values())
-    # gradients: EVERY parameter against float64.  The yardstick is the reference's own fp32 arithmetic: the CPU oracle in
-    # fp32 reproduces the reference fixture bit for bit on every stored tensor (asserted), so its distance to float64 is
-    # the reference's distance for all 276 / 444 tensors.  The HIP path must be within 1e-4 l2rel of the truth, or no
-    # further from it than 3x the reference is.  Tensors whose true gradient is zero (the stage norms' biases: a per-channel
-    # shift in front of a training-mode BatchNorm) are held to the fp32 noise floor instead.
-    f32 = f64ref.run(tag, dtype=torch.float32)
-    for k in g.files:
-        if k.startswith('grad::'):
-            # bit-identical on the CPU that made the fixture; another host's vector width may move the last bits
-            assert f64ref.l2rel(f64ref.sample(f32['grads'][k[6:]]), T(g[k])) <= 1e-5, f'oracle fp32 != reference fixture for {k}'
-    total64 = torch.sqrt(sum((v.double() ** 2).sum() for v in f64['grads'].values())).item()
+    # Gradients of EVERY parameter.  ReLU / LeakyReLU and bilinear sampling have kinks: an element whose pre-activation (or
+    # sampling coordinate) lies within fp32 rounding of the kink takes one slope or the other depending on the last bits, in
+    # ANY fp32 implementation — the reference on CPU flips 2-3 of its 4.1 M activations against float64 at this fixture
+    # (depending on its thread count), and ONE flipped element of the 2 x 1536 x 2 x 3 top-level map moves every stage-3
+    # gradient by 4e-3 (tests/test_oracle_golden.py::test_fp32_gradient_gap_is_kink_decisions).  So the float64 oracle is
+    # evaluated with the HIP run's own decisions at every kink (oracle.KINK_FORCE; only rounding-level moves are accepted:
+    # flipped pre-activations < 1e-4, sampling shifts < 1e-3 px) and the HIP gradients must then agree with it to 1e-4.
+    f64k = f64ref.run(tag, force=decisions)
+    st = f64k['force_stats']
+    print(f'[{tag}] kink decisions that differ from plain float64: {st["act_flipped"]} of {st["act_seen"]} activations '
+          f'(largest flipped |pre-activation| {st["max_flipped_preact"]:.1e}), {st["floor_flipped"]} of {st["floor_seen"]} sampling '
+          f'cells (largest shift {st["max_shift_px"]:.1e} px)')
+    assert st['max_flipped_preact'] <= 1e-4 and st['act_flipped'] <= 1e-5 * st['act_seen'] + 2, st
+    assert st['floor_flipped'] <= 1e-5 * st['floor_seen'] + 2, st
+    total64 = torch.sqrt(sum((v.double() ** 2).sum() for v in f64k['grads'].values())).item()
     table = []
     for k, p in params.items():
-        g64 = f64ref.sample(f64['grads'][k])
-        if g64.norm().item() < 1e-10 * total64:
+        gk = f64ref.sample(f64k['grads'][k])
+        if gk.norm().item() < 1e-10 * total64:                 # true gradient zero (stage-norm biases in front of a BatchNorm)
             assert f64ref.sample(p.grad).double().norm().item() <= 1e-6 * total64, (k, 'zero-gradient tensor above the noise floor')
             continue
-        table.append((k, f64ref.l2rel(f64ref.sample(p.grad), g64), f64ref.l2rel(f64ref.sample(f32['grads'][k]), g64)))
-    table.sort(key=lambda r: -r[1] / max(r[2], 1e-4 / 3))
-    print(f'[{tag}] gradient l2rel vs float64, {len(table)} tensors; worst by ratio to the reference (fp32 CPU):')
-    for k, e_hip, e_ref in table[:12]:
-        print(f'   {k:72s} HIP {e_hip:.2e}   reference fp32 {e_ref:.2e}')
-    rec['grad_worst_hip_vs_f64'] = max(e for _, e, _ in table)
-    rec['grad_worst_ref_vs_f64'] = max(r for _, _, r in table)
+        table.append((k, f64ref.l2rel(f64ref.sample(p.grad), gk), f64ref.l2rel(f64ref.sample(p.grad), f64ref.sample(f64['grads'][k]))))
+    table.sort(key=lambda r: -r[1])
+    print(f'[{tag}] gradient l2rel, {len(table)} tensors: worst vs float64 with the same kink decisions (| vs plain float64):')
+    for k, e, e_plain in table[:8]:
+        print(f'   {k:72s} {e:.2e} | {e_plain:.2e}')
+    rec['grad_worst_vs_f64_same_kinks'] = table[0][1]
+    rec['grad_worst_vs_f64_plain'] = max(r[2] for r in table)
+    rec['kink_stats'] = st
     rec['grad_table'] = table[:40]
     _log_parity(tag, rec)
-    bad = [(k, e, r) for k, e, r in table if e > max(1e-4, 3.0 * r)]
+    bad = [(k, e) for k, e, _ in table if e > 1e-4]
     assert not bad, bad[:8]
+    f64 = f64k
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())).item()
     assert abs(total - total64) <= 1e-4 * total64, (total, total64)
 

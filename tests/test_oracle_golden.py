@@ -262,3 +262,26 @@ def test_reference_fixture_vs_float64_oracle(golden, tag):
         assert e <= (2e-3 if any(s in k for s in soft) else 1e-4), (k, e)
     if tag == 'e2e_L_A':
         assert max(worst.values()) >= 1e-4          # the point: the reference itself is not within 1e-4 of the truth
+
+
+def test_fp32_gradient_gap_is_kink_decisions():
+    """Why two correct fp32 evaluations of this network differ by up to ~5e-3 on some gradients while every layer is good
+    to 1e-6: ReLU / LeakyReLU (and bilinear sampling) have kinks, and the 64 x 96 Swin-L fixture has activations within
+    2.5e-6 of zero.  The fp32 oracle (= the reference's arithmetic) flips a handful of its 4.1 M activation decisions against
+    float64; with exactly those decisions imposed on the float64 evaluation (oracle.KINK_FORCE) the SAME fp32 gradients agree
+    with float64 to 1e-4 on every tensor.  tests/test_model_gpu.py applies the identical procedure to the HIP path."""
+    import f64ref
+    tag = 'e2e_L_A'
+    r32 = f64ref.run(tag, dtype=torch.float32, record=True)
+    forced = f64ref.run(tag, force=r32['decisions'])
+    st = forced['force_stats']
+    assert st['act_seen'] > 4e6 and st['floor_seen'] > 2e6
+    assert st['act_flipped'] <= 12 and st['max_flipped_preact'] <= 1e-5, st          # a handful, all at rounding level
+    assert st['floor_flipped'] <= 4 and st['max_shift_px'] <= 1e-4, st
+    total = torch.sqrt(sum((v.double() ** 2).sum() for v in forced['grads'].values())).item()
+    worst = 0.0
+    for k, v in forced['grads'].items():
+        if v.norm().item() < 1e-10 * total:
+            continue
+        worst = max(worst, f64ref.l2rel(r32['grads'][k], v))
+    assert worst <= 1e-4, worst
