@@ -33,6 +33,8 @@ def parse():
     ap.add_argument('--height', type=int, default=352)
     ap.add_argument('--width', type=int, default=1120)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--allreduce-dtype', default='fp32', choices=['fp32', 'bf16'], help='gradient all-reduce wire format (N > 1)')
+    ap.add_argument('--bucket-mb', type=float, default=None, help='DDP bucket size in MiB (default 64)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the second (HIP-event profiled) pass')
     ap.add_argument('--profile-steps', type=int, default=5, help='steps of the separate per-kernel timing pass')
@@ -148,7 +150,8 @@ def build_job(args, cfg, dev, rank, dtype):
     model.init_weights()
     model = model.to(dev).train()
     optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
-    ddp = FlatDDP(model, optimizer.arena)
+    ddp = FlatDDP(model, optimizer.arena, bucket_mb=args.bucket_mb,
+                  grad_dtype=torch.bfloat16 if args.allreduce_dtype == 'bf16' else None)
     batch = synthetic_batch(per_gpu, args.height, args.width, seed=1234 + rank, device=dev)
     if 'ddad' in args.config:                                # per-sample camera heights (loading.py:923-932)
         batch['height'] = torch.full((per_gpu,), 1.56, device=dev)
@@ -244,7 +247,7 @@ def main():
             'config': {'workload': f'{args.config[:-3]}: DepthFormer-Swin{"T" if cfg.model.backbone.embed_dims == 96 else "L"} + '
                                    f'GEDepth-{"Adaptive" if "dynamic_pe_neck" in cfg.model else "Vanilla"}, '
                                    f'{args.height}x{args.width}, {per_gpu} img/GPU, full train step',
-                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'last_loss': round(float(loss), 5),
+                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'last_loss': round(float(loss), 5),
                        'params': int(optimizer.arena.numel)},
         }
         if prof:

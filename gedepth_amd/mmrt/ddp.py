@@ -21,9 +21,19 @@ import torch.nn as nn
 
 class FlatDDP(nn.Module):
 
-    def __init__(self, module, arena, bucket_mb=64, process_group=None, overlap=True, broadcast=True):
+    def __init__(self, module, arena, bucket_mb=None, process_group=None, overlap=True, broadcast=True, grad_dtype=None):
+        """``grad_dtype=torch.bfloat16`` halves the bytes on xGMI (1.10 GB -> 0.55 GB per step for Swin-L): each
+        bucket is rounded into a bf16 staging buffer, all-reduced (sum) and widened back into the fp32 arena with the 1/world
+        scale; the default (None) reduces the fp32 arena slices in place.  ``bucket_mb`` / ``GE_DDP_BUCKET_MB`` size the
+        buckets (default 64 MiB: per-link bandwidth ~153 GB/s, so a 64 MiB ring step is ~0.1 ms per hop and latency-amortised)."""
         super().__init__()
         self.module, self.arena, self.group, self.overlap = module, arena, process_group, overlap
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get('GE_DDP_BUCKET_MB', 64))
+        if grad_dtype is None and os.environ.get('GE_DDP_GRAD_DTYPE', '') in ('bf16', 'bfloat16'):
+            grad_dtype = torch.bfloat16
+        assert grad_dtype in (None, torch.float32, torch.bfloat16)
+        self.grad_dtype = None if grad_dtype == torch.float32 else grad_dtype
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # GE_DDP_FORCE=1 exercises the bucket / collective machinery on a single rank (1-GPU validation of the N-GPU path)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('GE_DDP_FORCE') == '1')
@@ -72,10 +82,14 @@ class FlatDDP(nn.Module):
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         buf = self.arena.flat_grad[lo:hi]
-        if self.backend == 'nccl':
+        if self.grad_dtype is not None:                       # reduced-precision exchange through a staging buffer
+            stage = buf.to(self.grad_dtype)
+            work = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append((work, ('widen', buf, stage)))
+        elif self.backend == 'nccl':
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:
-            self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
+            self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), ('scale', buf, None)))
 
     def _launch_ready(self):
         while self._next < len(self.buckets) and self._pending[self._next] <= 0:
@@ -89,10 +103,14 @@ class FlatDDP(nn.Module):
         while self._next < len(self.buckets):            # parameters without a gradient this step, or overlap off
             self._launch(self._next)
             self._next += 1
-        for work, buf in self._works:
+        for work, post in self._works:
             work.wait()
-            if buf is not None:
-                buf.div_(self.world)
+            if post is not None:
+                kind, buf, stage = post
+                if kind == 'widen':
+                    torch.mul(stage, 1.0 / self.world, out=buf)          # bf16 -> fp32 with the averaging scale, one pass
+                else:
+                    buf.div_(self.world)
         self._reset()
 
     # ------------------------------------------------------------------ module protocol

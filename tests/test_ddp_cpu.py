@@ -117,6 +117,41 @@ def test_flat_ddp_gloo_world2(tmp_path):
     assert r0['log'] == r1['log']
 
 
+def _worker_bf16(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(7)
+    model = Toy()
+    opt = ArenaSGD(model)
+    ddp = FlatDDP(model, opt.arena, bucket_mb=0.0005, grad_dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(8, 8, generator=g), torch.randn(8, 1, generator=g)
+    batch = dict(x=X[rank * 4:(rank + 1) * 4], y=Y[rank * 4:(rank + 1) * 4])
+    opt.zero_grad()
+    out = ddp.train_step(batch)
+    out['loss'].backward()
+    local = opt.arena.flat_grad.clone()
+    ddp.finish()
+    torch.save(dict(local=local, reduced=opt.arena.flat_grad.clone()), os.path.join(tmp, f'b{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_bf16_gradient_exchange(tmp_path):
+    """grad_dtype=bf16 (half the xGMI bytes): every rank ends with mean over ranks of the bf16-rounded
+    local gradients, widened back into the fp32 arena — identical on all ranks, within bf16 rounding of the fp32 mean."""
+    port = free_port()
+    mp.spawn(_worker_bf16, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'b{i}.pt', weights_only=False) for i in range(2))
+    assert torch.equal(r0['reduced'], r1['reduced'])
+    exact = 0.5 * (r0['local'] + r1['local'])
+    expect = ((r0['local'].bfloat16() + r1['local'].bfloat16()).float()) * 0.5         # the wire format's own arithmetic
+    assert torch.allclose(r0['reduced'], expect, rtol=0, atol=1e-6 * expect.abs().max().item() + 1e-12) or \
+        (r0['reduced'] - exact).abs().max() <= 2 ** -7 * exact.abs().max()
+    assert (r0['reduced'] - exact).abs().max() <= 2 ** -7 * exact.abs().max()
+    assert not torch.equal(r0['reduced'], exact)                      # really went through bf16
+
+
 def test_deferred_log_vars_single_process():
     lv = DeferredLogVars(['a', 'b'], torch.tensor([1.5, 2.5]))
     assert lv.tensor() is not None
