@@ -35,6 +35,8 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--allreduce-dtype', default='fp32', choices=['fp32', 'bf16'], help='gradient all-reduce wire format (N > 1)')
     ap.add_argument('--bucket-mb', type=float, default=None, help='DDP bucket size in MiB (default 64)')
+    ap.add_argument('--attn', default='auto', choices=['auto', 'fp8'],
+                    help="window attention: 'fp8' = e4m3 MFMA forward contractions (BASELINE.json configs[4]); 'auto' = bf16 MFMA")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the second (HIP-event profiled) pass')
     ap.add_argument('--profile-steps', type=int, default=5, help='steps of the separate per-kernel timing pass')
@@ -149,6 +151,10 @@ def build_job(args, cfg, dev, rank, dtype):
     model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     model.init_weights()
     model = model.to(dev).train()
+    if args.attn == 'fp8' and dtype == 'bf16':
+        for mod in model.modules():
+            if hasattr(mod, 'kernel_variant'):
+                mod.kernel_variant = 3
     optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
     ddp = FlatDDP(model, optimizer.arena, bucket_mb=args.bucket_mb,
                   grad_dtype=torch.bfloat16 if args.allreduce_dtype == 'bf16' else None)
@@ -247,7 +253,7 @@ def main():
             'config': {'workload': f'{args.config[:-3]}: DepthFormer-Swin{"T" if cfg.model.backbone.embed_dims == 96 else "L"} + '
                                    f'GEDepth-{"Adaptive" if "dynamic_pe_neck" in cfg.model else "Vanilla"}, '
                                    f'{args.height}x{args.width}, {per_gpu} img/GPU, full train step',
-                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'last_loss': round(float(loss), 5),
+                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'window_attention': 'fp8-e4m3 mfma fwd' if args.attn == 'fp8' else 'bf16 mfma', 'last_loss': round(float(loss), 5),
                        'params': int(optimizer.arena.numel)},
         }
         if prof:

@@ -263,7 +263,7 @@ static int bwd_wg_per_head(const WinGeom& g) {
 
 // implemented in window_attn_mfma.hip
 int ge_window_attn_fwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, void* out, const WinGeom& g,
-                            float scale, hipStream_t s);
+                            float scale, bool fp8, hipStream_t s);
 int ge_window_attn_bwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, const void* d_out, void* d_qkv,
                             float* workspace, const WinGeom& g, float scale, int wg_per_head, hipStream_t s);
 extern const int ge_window_attn_mfma_available;
@@ -284,9 +284,9 @@ extern "C" int ge_window_attn_fwd(const void* qkv, const float* qkv_bias, const 
   if (items == 0) return GE_OK;
   if (variant == 0) variant = (dtype == GE_BF16 && (ge_window_attn_mfma_available & 1)) ? 2 : 1;
   hipStream_t s = ge_stream(stream);
-  if (variant == 2) {
+  if (variant == 2 || variant == 3) {                          // 3: fp8 (e4m3) MFMA contractions, BASELINE.json configs[4]
     if (dtype != GE_BF16 || !(ge_window_attn_mfma_available & 1)) return GE_ERR_UNSUPPORTED;
-    return ge_window_attn_fwd_mfma(qkv, qkv_bias, bias_table, out, g, scale, s);
+    return ge_window_attn_fwd_mfma(qkv, qkv_bias, bias_table, out, g, scale, variant == 3, s);
   }
   if (variant != 1) return GE_ERR_BAD_ARG;
   if (dtype == GE_F32)
@@ -314,7 +314,7 @@ extern "C" int ge_window_attn_bwd(const void* qkv, const float* qkv_bias, const 
   }
   const int wph = bwd_wg_per_head(g);
   if (variant == 0) variant = (dtype == GE_BF16 && (ge_window_attn_mfma_available & 2)) ? 2 : 1;
-  if (variant == 2) {
+  if (variant == 2 || variant == 3) {                          // the fp8 forward differentiates through the bf16 MFMA backward
     if (dtype != GE_BF16 || !(ge_window_attn_mfma_available & 2)) return GE_ERR_UNSUPPORTED;
     e = ge_window_attn_bwd_mfma(qkv, qkv_bias, bias_table, d_out, d_qkv, (float*)workspace, g, scale, wph, s);
     if (e) return e;

@@ -30,6 +30,42 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// ---- fp8 (OCP e4m3 on gfx950) variant of the two forward contractions: v_mfma_f32_32x32x16_fp8_fp8 has the same
+// (lane, k-slot) operand map as the bf16 instruction (8 values per lane and K = 16 step), so a bf16x8 fragment converts in
+// registers: value * scale -> v_cvt_pk_fp8_f32.  Scales are per (window, head) and per operand: 448 / amax of the staged
+// tile (the e4m3 maximum), folded back into the score scale / output multiplier.  BASELINE.json configs[4].
+__device__ __forceinline__ f32x16 mfma_fp8(long a, long b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ long fp8x8_from_f32(const float v[8]) {
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+__device__ __forceinline__ long fp8x8_from_bf16(bf16x8 x, float scale) {
+  const uint4 u = __builtin_bit_cast(uint4, x);
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16) * scale; v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u) * scale; }
+  return fp8x8_from_f32(v);
+}
+#define FP8_MAX 448.0f
+// 448 / max |x| over a staged [rows][ld] bf16 tile (first `cols` columns), wave-uniform; 1 for an all-zero tile
+__device__ __forceinline__ float tile_fp8_scale(const bf16_t* tile, int ld, int rows, int cols, int lane) {
+  float m = 0.f;
+  for (int i = lane; i < rows * cols; i += 64) {
+    const int r = i / cols, cc = i - r * cols;
+    m = fmaxf(m, fabsf(bf2f(tile[r * ld + cc])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m > 0.f ? FP8_MAX / m : 1.f;
+}
+
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // -> v_cvt_pk_bf16_f32 (round-to-nearest-even)
   bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -159,6 +195,27 @@ __device__ __forceinline__ void st_tiles(const bf16_t* A_rows, const bf16_t* B_r
   }
 }
 
+// fp8 version of st_tiles: operands converted fragment by fragment with the tile scales sa (A rows) / sb (B rows); the
+// accumulators hold (sa * sb) * S^T
+__device__ __forceinline__ void st_tiles_fp8(const bf16_t* A_rows, const bf16_t* B_rows, int c, int hi, float sa, float sb,
+                                             f32x16 acc[2][2]) {
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[kt][qt][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const long a0 = fp8x8_from_bf16(row8(A_rows, c, ks * 16 + hi * 8), sa), a1 = fp8x8_from_bf16(row8(A_rows, 32 + c, ks * 16 + hi * 8), sa);
+    const long b0 = fp8x8_from_bf16(row8(B_rows, c, ks * 16 + hi * 8), sb), b1 = fp8x8_from_bf16(row8(B_rows, 32 + c, ks * 16 + hi * 8), sb);
+    acc[0][0] = mfma_fp8(a0, b0, acc[0][0]);
+    acc[0][1] = mfma_fp8(a0, b1, acc[0][1]);
+    acc[1][0] = mfma_fp8(a1, b0, acc[1][0]);
+    acc[1][1] = mfma_fp8(a1, b1, acc[1][1]);
+  }
+}
+
 // scores -> normalised probabilities, in place.  Lane owns query columns c (qt=0) and 32+c (qt=1).
 __device__ __forceinline__ void softmax_cols(f32x16 acc[2][2], const float* bias, const uint32_t* meta, int c, int hi,
                                              float scale, bool use_mask) {
@@ -222,6 +279,7 @@ struct WinSmemMfmaFwd {
   WinMeta m;
 };
 
+template <bool FP8>
 __global__ void __launch_bounds__(64) window_attn_fwd_mfma_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                              const float* __restrict__ bias_table, bf16_t* __restrict__ out,
                                                              WinGeom g, float scale) {
@@ -244,7 +302,17 @@ __global__ void __launch_bounds__(64) window_attn_fwd_mfma_k(const bf16_t* __res
   __syncthreads();
 
   f32x16 acc[2][2];
-  st_tiles(sm.k, sm.q, c, hi, acc);
+  float out_mul = 1.f;
+  float v_scale = 1.f;
+  if constexpr (FP8) {
+    const float sk = tile_fp8_scale(sm.k, RLD, 64, HD, lane), sq = tile_fp8_scale(sm.q, RLD, 64, HD, lane);
+    v_scale = tile_fp8_scale(sm.vt, VLD, HD, 64, lane);
+    st_tiles_fp8(sm.k, sm.q, c, hi, sk, sq, acc);
+    scale = scale / (sk * sq);
+    out_mul = 1.f / (v_scale * 256.f);                          // probabilities go to fp8 as P * 256 (<= 256 < 448)
+  } else {
+    st_tiles(sm.k, sm.q, c, hi, acc);
+  }
   const bool use_mask = g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
   softmax_cols(acc, sm.bias, sm.m.meta, c, hi, scale, use_mask);
 
@@ -261,15 +329,24 @@ __global__ void __launch_bounds__(64) window_attn_fwd_mfma_k(const bf16_t* __res
       const int kb = kt * 32 + 16 * s + 4 * hi;
       const uint2 lo = *(const uint2*)(sm.vt + c * VLD + kb), hi8 = *(const uint2*)(sm.vt + c * VLD + kb + 8);
       const bf16x8 a = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi8.x, hi8.y));
-      o[0] = mfma_bf16(a, pack8(acc[kt][0], 8 * s), o[0]);
-      o[1] = mfma_bf16(a, pack8(acc[kt][1], 8 * s), o[1]);
+      if constexpr (FP8) {
+        const long a8 = fp8x8_from_bf16(a, v_scale);
+        float p0[8], p1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { p0[e] = acc[kt][0][8 * s + e] * 256.f; p1[e] = acc[kt][1][8 * s + e] * 256.f; }
+        o[0] = mfma_fp8(a8, fp8x8_from_f32(p0), o[0]);
+        o[1] = mfma_fp8(a8, fp8x8_from_f32(p1), o[1]);
+      } else {
+        o[0] = mfma_bf16(a, pack8(acc[kt][0], 8 * s), o[0]);
+        o[1] = mfma_bf16(a, pack8(acc[kt][1], 8 * s), o[1]);
+      }
     }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = qt * 32 + c;
     if (q < WT) {
       const int dst = sm.m.tok[q];
-      if (dst >= 0) store_cols(o[qt], 1.f, out + ((long)b * L + dst) * g.C + head * HD, hi);
+      if (dst >= 0) store_cols(o[qt], out_mul, out + ((long)b * L + dst) * g.C + head * HD, hi);
     }
   }
 }
@@ -424,9 +501,12 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_k(const bf16_t* __res
 extern const int ge_window_attn_mfma_available = 3;   // bit0: forward, bit1: backward
 
 int ge_window_attn_fwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, void* out, const WinGeom& g,
-                            float scale, hipStream_t s) {
+                            float scale, bool fp8, hipStream_t s) {
   const long items = (long)g.B * g.nWh * g.nWw * g.nH;
-  window_attn_fwd_mfma_k<<<(unsigned)items, 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table, (bf16_t*)out, g, scale);
+  if (fp8)
+    window_attn_fwd_mfma_k<true><<<(unsigned)items, 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table, (bf16_t*)out, g, scale);
+  else
+    window_attn_fwd_mfma_k<false><<<(unsigned)items, 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table, (bf16_t*)out, g, scale);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

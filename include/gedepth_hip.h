@@ -45,7 +45,9 @@ int ge_abi_version(void);
  *   bias_table (169, nH)      f32   relative_position_bias_table
  *   out        (B, H*W, C)    dtype; channel = head*32 + d  (the transpose(1,2).reshape of :221)
  * head_dim is fixed at 32 (true for every Swin stage of the reference), window 7, shift in {0,3}.
- * `variant`: 0 = auto, 1 = exact-fp32 VALU kernel, 2 = bf16 MFMA kernel (dtype must be GE_BF16).
+ * `variant`: 0 = auto, 1 = exact-fp32 VALU kernel, 2 = bf16 MFMA kernel (dtype must be GE_BF16), 3 = fp8 (OCP e4m3) MFMA
+ *   forward on bf16 storage: QK^T and PV on v_mfma_f32_32x32x16_fp8_fp8 with per-(window, head) operand scales
+ *   448 / amax (BASELINE.json configs[4]); its backward is variant 2's.
  */
 int ge_window_attn_fwd(const void* qkv, const float* qkv_bias, const float* bias_table, void* out,
                        int B, int H, int W, int nH, int shift, float scale, int dtype, int variant,

@@ -170,6 +170,43 @@ def test_window_attention_mfma_vs_exact(dev, geom, shift):
     assert (dq - dq_ref).abs().mean().item() < 6e-3 * dq_ref.abs().mean().item() + 1e-5
 
 
+@pytest.mark.parametrize('geom,shift', [((2, 11, 35, 3), 0), ((2, 11, 35, 3), 3), ((1, 22, 70, 12), 3), ((2, 10, 9, 6), 0)])
+def test_window_attention_fp8_forward(dev, geom, shift):
+    """BASELINE.json configs[4]: the fp8 (OCP e4m3) MFMA forward (variant 3: QK^T and PV on v_mfma_f32_32x32x16_fp8_fp8, per
+    (window, head) operand scales 448 / amax, probabilities as P * 256) against the exact-fp32 kernel on the same
+    bf16-rounded inputs.  TOLERANCE RESTATED for fp8: e4m3 keeps 3 mantissa bits (relative step 2^-3 at worst, 2^-4 typ.):
+    scores carry ~2^-4 * |q||k| noise averaged over 32 products and the softmax-weighted sum over <= 49 keys, which leaves
+    the output within 6e-2 of its scale at worst and 1.5e-2 on average (bf16 MFMA: 2e-2 / 4e-3).  The backward is the bf16
+    MFMA kernel's (gradients of the bf16 function at the same inputs) and is checked against variant 2 bit for bit."""
+    from gedepth_amd.kernels import window_attention
+    B, H, W, nH = geom
+    C = nH * 32
+    g = gen(B * 1000 + H * 10 + W + shift + 5)
+    qkv = torch.randn(B, H * W, 3 * C, generator=g).bfloat16()
+    qb = (0.3 * torch.randn(3 * C, generator=g)).bfloat16().float()
+    tab = 0.5 * torch.randn(169, nH, generator=g)
+    go = torch.randn(B, H * W, C, generator=g).bfloat16()
+
+    def run(dt, variant):
+        q = qkv.to(dev).to(dt).requires_grad_(True)
+        b = qb.to(dev).requires_grad_(True)
+        t = tab.to(dev).requires_grad_(True)
+        o = window_attention(q, b, t, H, W, nH, shift, 32 ** -0.5, variant)
+        o.backward(go.to(dev).to(dt))
+        return o.float(), q.grad.float(), b.grad, t.grad
+    o_ref, _, _, _ = run(torch.float32, 1)
+    o8, dq8, db8, dt8 = run(torch.bfloat16, 3)
+    o16, dq16, db16, dt16 = run(torch.bfloat16, 2)
+    scale = o_ref.abs().max().item()
+    err = (o8 - o_ref).abs()
+    print(f'\nfp8 forward {geom} shift {shift}: max err {err.max().item() / scale:.3e} of scale, mean {err.mean().item() / o_ref.abs().mean().item():.3e}; '
+          f'bf16 MFMA: max {(o16 - o_ref).abs().max().item() / scale:.3e}')
+    assert err.max().item() <= 6e-2 * scale, err.max().item() / scale
+    assert err.mean().item() <= 1.5e-2 * o_ref.abs().mean().item() + 1e-4
+    assert err.mean().item() > (o16 - o_ref).abs().mean().item()            # it really is the lower-precision path
+    assert torch.equal(dq8, dq16) and torch.equal(db8, db16) and torch.equal(dt8, dt16)
+
+
 def test_window_attention_mfma_default_for_bf16(dev):
     """variant 0 (auto) must pick the MFMA kernel for bf16 storage and agree with it bit-for-bit."""
     from gedepth_amd.kernels import window_attention
