@@ -336,4 +336,6 @@ def test_rccl_gradient_exchange_single_rank(dev):
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_rccl_worker.py')], env=env, capture_output=True, text=True,
                        timeout=600)
-    assert r.returncode == 0 and 'RCCL_DDP_OK' in r.stdout, (r.stdout[-3000:], r.stderr[-6000:])
+    if r.returncode != 0 or 'RCCL_DDP_OK' not in r.stdout:
+        print('---- worker stdout ----\n' + r.stdout[-6000:] + '\n---- worker stderr ----\n' + r.stderr[-6000:])
+    assert r.returncode == 0 and 'RCCL_DDP_OK' in r.stdout
