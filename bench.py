@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--bucket-mb', type=float, default=None, help='DDP bucket size in MiB (default 64)')
     ap.add_argument('--attn', default='auto', choices=['auto', 'fp8'],
                     help="window attention: 'fp8' = e4m3 MFMA forward contractions (BASELINE.json configs[4]); 'auto' = bf16 MFMA")
+    ap.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'],
+                    help='nhwc: channels-last conv stack (depth.models.utils.to_channels_last): no MIOpen layout transposes, tokens <-> maps are views')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true', help='skip the second (HIP-event profiled) pass')
     ap.add_argument('--profile-steps', type=int, default=5, help='steps of the separate per-kernel timing pass')
@@ -151,6 +153,9 @@ def build_job(args, cfg, dev, rank, dtype):
     model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     model.init_weights()
     model = model.to(dev).train()
+    if args.layout == 'nhwc':
+        from gedepth_amd.depth.models.utils import to_channels_last
+        to_channels_last(model)
     if args.attn == 'fp8' and dtype == 'bf16':
         for mod in model.modules():
             if hasattr(mod, 'kernel_variant'):
@@ -253,7 +258,7 @@ def main():
             'config': {'workload': f'{args.config[:-3]}: DepthFormer-Swin{"T" if cfg.model.backbone.embed_dims == 96 else "L"} + '
                                    f'GEDepth-{"Adaptive" if "dynamic_pe_neck" in cfg.model else "Vanilla"}, '
                                    f'{args.height}x{args.width}, {per_gpu} img/GPU, full train step',
-                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'window_attention': 'fp8-e4m3 mfma fwd' if args.attn == 'fp8' else 'bf16 mfma', 'last_loss': round(float(loss), 5),
+                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'layout': args.layout, 'window_attention': 'fp8-e4m3 mfma fwd' if args.attn == 'fp8' else 'bf16 mfma', 'last_loss': round(float(loss), 5),
                        'params': int(optimizer.arena.numel)},
         }
         if prof:

@@ -1,0 +1,540 @@
+// Channels-last (NHWC) variants of the map kernels of the HAHI neck / PE necks / DenseDepth head.
+//
+// MIOpen's bf16 implicit-GEMM convolutions are NHWC inside; on NCHW tensors it brackets every call with batched_transpose
+// kernels (4.9 ms of the 92 ms KITTI step, profiles/r1_bench_kernel_stats.csv) and the HAHI neck pays two more transposing
+// passes to get tokens (B, H*W, C) out of / into maps.  A channels-last map (B, C, H, W) with strides (HWC, 1, WC, C) IS the
+// token matrix (B*H*W, C): 1x1 convs, the deformable attention and the 3x3 convs then share one layout and nothing is
+// transposed.  These kernels are what the path needs on that layout:
+//   ge_bn_act_nhwc_*     training-mode BatchNorm2d + (Leaky)ReLU (mmcv ConvModule, necks/hahi.py:150-166): per-channel
+//                        statistics are COLUMN sums of the (rows, C) matrix
+//   ge_bias_act_nhwc_*   conv bias + LeakyReLU (densedepth_head.py:14-27, pemask_neck.py:36-42), bias gradient = column sums
+//   ge_bilinear_nhwc_*   F.interpolate(bilinear), both align_corners conventions, 16 bytes of channels per lane
+//   ge_concat_rows_*     torch.cat([a, b], 1) of two channels-last maps / token matrices with the HAHI glue folded in:
+//                        dropout(tokens) + identity written into its slot (hahi.py:326-346)
+//   ge_add_rows          tokens + positional embedding (fp32 (N, C), broadcast over the batch; hahi.py:303-306)
+// All HBM-bound streaming work: 16-byte accesses along the channel dimension, fp32 arithmetic, no MFMA.
+#include "common.h"
+
+#define NH_MAXLANES 256
+
+// ---------------------------------------------------------------------------------------------- column sums
+// K column sums of f_k(row element) over a (R, C) matrix: thread = (row slot, channel vector); fp32 per thread over its rows,
+// LDS across the row slots of a workgroup, one fp64 atomic per (workgroup, channel) into ws[k * C + c].
+template <int K, int VN>
+__device__ __forceinline__ void nh_col_commit(float (&acc)[K][VN], double* __restrict__ ws, int C, int lpr, int rpi, int c0) {
+  __shared__ float sm[K][NH_MAXLANES][VN];
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int v = 0; v < VN; ++v) sm[k][t][v] = acc[k][v];
+  __syncthreads();
+  if (t < lpr) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int v = 0; v < VN; ++v) {
+        float s = 0.f;
+        for (int j = 0; j < rpi; ++j) s += sm[k][j * lpr + t][v];
+        atomicAdd(&ws[(long)k * C + c0 + v], (double)s);
+      }
+  }
+}
+static inline unsigned nh_grid_rows(long R, int rpi) {
+  long b = (R + (long)rpi * 8 - 1) / ((long)rpi * 8);
+  if (b < 1) b = 1;
+  if (b > 4096) b = 4096;
+  return (unsigned)b;
+}
+
+// ============================================================================ BatchNorm2d (training) + (Leaky)ReLU
+template <typename T>
+__global__ void __launch_bounds__(256) bn_stats_nhwc_k(const T* __restrict__ x, double* __restrict__ ws, int C, long R, int lpr, int rpi) {
+  constexpr int VN = V8<T>::N;
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  const int c0 = lane * VN;
+  float acc[2][VN];
+#pragma unroll
+  for (int v = 0; v < VN; ++v) { acc[0][v] = 0.f; acc[1][v] = 0.f; }
+  if (rs < rpi)
+    for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
+      float v[VN];
+      V8<T>::ld(x + r * C + c0, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) { acc[0][k] += v[k]; acc[1][k] += v[k] * v[k]; }
+    }
+  nh_col_commit<2, VN>(acc, ws, C, lpr, rpi, c0);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_nhwc_k(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y, int C,
+                                                       long nvec, int lpr, float slope) {
+  constexpr int VN = V8<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % lpr) * VN;
+    float v[VN];
+    V8<T>::ld(x + i * VN, v);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { const float tv = v[k] * coef[c0 + k] + coef[C + c0 + k]; v[k] = tv > 0.f ? tv : tv * slope; }
+    V8<T>::st(y + i * VN, v);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_stats_nhwc_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                           const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                           double* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
+  constexpr int VN = V8<T>::N;
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  const int c0 = lane * VN;
+  float mu[VN], rsd[VN], acc[2][VN];
+#pragma unroll
+  for (int v = 0; v < VN; ++v) { mu[v] = save_mean[c0 + v]; rsd[v] = save_rstd[c0 + v]; acc[0][v] = 0.f; acc[1][v] = 0.f; }
+  if (rs < rpi)
+    for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
+      float g[VN], yv[VN], xv[VN];
+      V8<T>::ld(dy + r * C + c0, g);
+      V8<T>::ld(y + r * C + c0, yv);
+      V8<T>::ld(x + r * C + c0, xv);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) {
+        const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
+        acc[0][k] += gg;
+        acc[1][k] += gg * ((xv[k] - mu[k]) * rsd[k]);
+      }
+    }
+  nh_col_commit<2, VN>(acc, ws, C, lpr, rpi, c0);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_nhwc_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                           const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                           const float* __restrict__ coef, T* __restrict__ dx, int C, long nvec, int lpr,
+                                                           float slope) {
+  constexpr int VN = V8<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % lpr) * VN;
+    float g[VN], yv[VN], xv[VN];
+    V8<T>::ld(dy + i * VN, g);
+    V8<T>::ld(y + i * VN, yv);
+    V8<T>::ld(x + i * VN, xv);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+      const int c = c0 + k;
+      const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
+      g[k] = coef[c] * (gg - coef[C + c] - ((xv[k] - save_mean[c]) * save_rstd[c]) * coef[2 * C + c]);
+    }
+    V8<T>::st(dx + i * VN, g);
+  }
+}
+
+// finalize kernels: same arithmetic as the NCHW path (norm.hip), restated here because the two files are separate TUs
+__global__ void __launch_bounds__(256) bn_finalize_nhwc_k(const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_rstd, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ coef, int C, double n,
+                                                          float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = ws[c] / n;
+  double var = ws[C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  save_mean[c] = (float)mean;
+  save_rstd[c] = rstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+  const float a = gamma[c] * rstd;
+  coef[c] = a;
+  coef[C + c] = beta[c] - (float)mean * a;
+}
+__global__ void __launch_bounds__(256) bn_bwd_finalize_nhwc_k(const double* __restrict__ ws, const float* __restrict__ gamma,
+                                                              const float* __restrict__ save_rstd, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef, int C, double n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)ws[c];
+  dgamma[c] = (float)ws[C + c];
+  coef[c] = gamma[c] * save_rstd[c];
+  coef[C + c] = (float)(ws[c] / n);
+  coef[2 * C + c] = (float)(ws[C + c] / n);
+}
+
+template <typename T> static bool nh_geom(int C, int& lpr, int& rpi) {
+  constexpr int VN = V8<T>::N;
+  if (C <= 0 || C % VN) return false;
+  lpr = C / VN;
+  if (lpr > NH_MAXLANES) return false;
+  rpi = NH_MAXLANES / lpr;
+  return true;
+}
+static inline bool nh_aligned(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+static inline unsigned nh_grid_vec(long nvec) { return ge_blocks(nvec, 256 * 4, 65536); }
+
+// workspace: same layout / size as ge_bn_workspace(C): double[2C] sums + float[3C] coefficients
+template <typename T>
+static int bn_nhwc_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                              float* running_mean, float* running_var, void* workspace, long R, int C, float eps, float momentum,
+                              float slope, hipStream_t s) {
+  int lpr, rpi;
+  if (!nh_geom<T>(C, lpr, rpi) || !nh_aligned(x, y)) return GE_ERR_UNSUPPORTED;
+  double* ws = (double*)workspace;
+  float* coef = (float*)(ws + 2 * C);
+  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s);
+  if (he != hipSuccess) return (int)he;
+  bn_stats_nhwc_k<T><<<nh_grid_rows(R, rpi), 256, 0, s>>>((const T*)x, ws, C, R, lpr, rpi);
+  GE_LAUNCH_CHECK();
+  bn_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, beta, save_mean, save_rstd, running_mean, running_var, coef, C, (double)R, eps, momentum);
+  GE_LAUNCH_CHECK();
+  const long nvec = R * lpr;
+  bn_apply_nhwc_k<T><<<nh_grid_vec(nvec), 256, 0, s>>>((const T*)x, coef, (T*)y, C, nvec, lpr, slope);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+template <typename T>
+static int bn_nhwc_bwd_launch(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                              const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, long R, int C, float slope,
+                              hipStream_t s) {
+  int lpr, rpi;
+  if (!nh_geom<T>(C, lpr, rpi) || !nh_aligned(dy, y, x, dx)) return GE_ERR_UNSUPPORTED;
+  double* ws = (double*)workspace;
+  float* coef = (float*)(ws + 2 * C);
+  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s);
+  if (he != hipSuccess) return (int)he;
+  bn_bwd_stats_nhwc_k<T><<<nh_grid_rows(R, rpi), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, ws, C, R, lpr, rpi, slope);
+  GE_LAUNCH_CHECK();
+  bn_bwd_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, save_rstd, dgamma, dbeta, coef, C, (double)R);
+  GE_LAUNCH_CHECK();
+  const long nvec = R * lpr;
+  bn_bwd_apply_nhwc_k<T><<<nh_grid_vec(nvec), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, coef, (T*)dx, C, nvec, lpr, slope);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+extern "C" int ge_bn_act_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                                  float* running_mean, float* running_var, void* workspace, long rows, int C, float eps,
+                                  float momentum, float slope, int dtype, void* stream) {
+  if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !workspace || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bn_nhwc_fwd_launch<float>(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, workspace, rows, C, eps, momentum, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bn_nhwc_fwd_launch<bf16_t>(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, workspace, rows, C, eps, momentum, slope, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+extern "C" int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                                  const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, long rows, int C,
+                                  float slope, int dtype, void* stream) {
+  if (!dy || !y || !x || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bn_nhwc_bwd_launch<float>(dy, y, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, workspace, rows, C, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bn_nhwc_bwd_launch<bf16_t>(dy, y, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, workspace, rows, C, slope, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+
+// ============================================================================================ bias + LeakyReLU
+template <typename T>
+__global__ void __launch_bounds__(256) bias_act_nhwc_fwd_k(T* __restrict__ x, const float* __restrict__ bias, long nvec, int lpr, float slope) {
+  constexpr int VN = V8<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % lpr) * VN;
+    float v[VN];
+    V8<T>::ld(x + i * VN, v);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { const float tv = v[k] + bias[c0 + k]; v[k] = tv > 0.f ? tv : tv * slope; }
+    V8<T>::st(x + i * VN, v);
+  }
+}
+// dx = dy * act'(y); d_bias (fp64 workspace, C doubles, zeroed by the launcher) = column sums of dx
+template <typename T>
+__global__ void __launch_bounds__(256) bias_act_nhwc_bwd_k(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                           double* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
+  constexpr int VN = V8<T>::N;
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  const int c0 = lane * VN;
+  float acc[1][VN];
+#pragma unroll
+  for (int v = 0; v < VN; ++v) acc[0][v] = 0.f;
+  if (rs < rpi)
+    for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
+      float g[VN], yv[VN];
+      V8<T>::ld(dy + r * C + c0, g);
+      V8<T>::ld(y + r * C + c0, yv);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) { g[k] = yv[k] > 0.f ? g[k] : g[k] * slope; acc[0][k] += g[k]; }
+      V8<T>::st(dx + r * C + c0, g);
+    }
+  nh_col_commit<1, VN>(acc, ws, C, lpr, rpi, c0);
+}
+__global__ void __launch_bounds__(256) nh_d2f_k(const double* __restrict__ a, float* __restrict__ b, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = (float)a[i];
+}
+extern "C" int ge_bias_act_nhwc_fwd(void* x, const float* bias, long rows, int C, float slope, int dtype, void* stream) {
+  if (!x || !bias || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
+  int lpr, rpi;
+  hipStream_t s = ge_stream(stream);
+  if (dtype == GE_F32) {
+    if (!nh_geom<float>(C, lpr, rpi) || !nh_aligned(x)) return GE_ERR_UNSUPPORTED;
+    bias_act_nhwc_fwd_k<float><<<nh_grid_vec(rows * lpr), 256, 0, s>>>((float*)x, bias, rows * lpr, lpr, slope);
+  } else if (dtype == GE_BF16) {
+    if (!nh_geom<bf16_t>(C, lpr, rpi) || !nh_aligned(x)) return GE_ERR_UNSUPPORTED;
+    bias_act_nhwc_fwd_k<bf16_t><<<nh_grid_vec(rows * lpr), 256, 0, s>>>((bf16_t*)x, bias, rows * lpr, lpr, slope);
+  } else {
+    return GE_ERR_UNSUPPORTED;
+  }
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+// workspace: C doubles
+extern "C" int ge_bias_act_nhwc_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, long rows, int C, float slope,
+                                    int dtype, void* stream) {
+  if (!dy || !y || !dx || !dbias || !workspace || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
+  int lpr, rpi;
+  hipStream_t s = ge_stream(stream);
+  double* ws = (double*)workspace;
+  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * C, s);
+  if (he != hipSuccess) return (int)he;
+  if (dtype == GE_F32) {
+    if (!nh_geom<float>(C, lpr, rpi) || !nh_aligned(dy, y, dx)) return GE_ERR_UNSUPPORTED;
+    bias_act_nhwc_bwd_k<float><<<nh_grid_rows(rows, rpi), 256, 0, s>>>((const float*)dy, (const float*)y, (float*)dx, ws, C, rows, lpr, rpi, slope);
+  } else if (dtype == GE_BF16) {
+    if (!nh_geom<bf16_t>(C, lpr, rpi) || !nh_aligned(dy, y, dx)) return GE_ERR_UNSUPPORTED;
+    bias_act_nhwc_bwd_k<bf16_t><<<nh_grid_rows(rows, rpi), 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, ws, C, rows, lpr, rpi, slope);
+  } else {
+    return GE_ERR_UNSUPPORTED;
+  }
+  GE_LAUNCH_CHECK();
+  nh_d2f_k<<<(C + 255) / 256, 256, 0, s>>>(ws, dbias, C);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+// ======================================================================================================= bilinear
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_nhwc_fwd_k(const T* __restrict__ in, T* __restrict__ out, int N, int Hi, int Wi, int Ho, int Wo,
+                                                           int C, int lpr, int align) {
+  constexpr int VN = V8<T>::N;
+  const float sy = ge_scale(Hi, Ho, align), sx = ge_scale(Wi, Wo, align);
+  const long total = (long)N * Ho * Wo * lpr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c0 = (int)(idx % lpr) * VN;
+    long t = idx / lpr;
+    const int x = (int)(t % Wo); t /= Wo;
+    const int y = (int)(t % Ho);
+    const long n = t / Ho;
+    const Lerp ly = ge_lerp(y, Hi, sy, align), lx = ge_lerp(x, Wi, sx, align);
+    const T* base = in + n * (long)Hi * Wi * C + c0;
+    float v00[VN], v01[VN], v10[VN], v11[VN], o[VN];
+    V8<T>::ld(base + ((long)ly.i0 * Wi + lx.i0) * C, v00);
+    V8<T>::ld(base + ((long)ly.i0 * Wi + lx.i1) * C, v01);
+    V8<T>::ld(base + ((long)ly.i1 * Wi + lx.i0) * C, v10);
+    V8<T>::ld(base + ((long)ly.i1 * Wi + lx.i1) * C, v11);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) o[k] = ly.w0 * (lx.w0 * v00[k] + lx.w1 * v01[k]) + ly.w1 * (lx.w0 * v10[k] + lx.w1 * v11[k]);
+    V8<T>::st(out + ((n * Ho + y) * (long)Wo + x) * C + c0, o);
+  }
+}
+// candidate output indices whose taps can touch input index X (same rule as the NCHW kernel, ground.hip)
+__device__ __forceinline__ void nh_cand_range(int X, int in, int out, float scale, bool align, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+  float a, b;
+  if (align) { a = ((float)X - 1.f) / scale; b = ((float)X + 1.f) / scale; }
+  else { a = ((float)X - 0.5f) / scale - 0.5f; b = ((float)X + 1.5f) / scale - 0.5f; }
+  lo = (int)floorf(a) - 1;
+  hi = (int)ceilf(b) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+// deterministic gather: each input element sums the contributions of the outputs whose taps touch it (no atomics)
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_nhwc_bwd_k(const T* __restrict__ gout, T* __restrict__ gin, int N, int Hi, int Wi, int Ho, int Wo,
+                                                           int C, int lpr, int align) {
+  constexpr int VN = V8<T>::N;
+  const float sy = ge_scale(Hi, Ho, align), sx = ge_scale(Wi, Wo, align);
+  const long total = (long)N * Hi * Wi * lpr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c0 = (int)(idx % lpr) * VN;
+    long t = idx / lpr;
+    const int X = (int)(t % Wi); t /= Wi;
+    const int Y = (int)(t % Hi);
+    const long n = t / Hi;
+    int ylo, yhi, xlo, xhi;
+    nh_cand_range(Y, Hi, Ho, sy, align, ylo, yhi);
+    nh_cand_range(X, Wi, Wo, sx, align, xlo, xhi);
+    const T* g = gout + n * (long)Ho * Wo * C + c0;
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const Lerp ly = ge_lerp(oy, Hi, sy, align);
+      const float wy = (ly.i0 == Y ? ly.w0 : 0.f) + (ly.i1 == Y ? ly.w1 : 0.f);
+      if (wy == 0.f) continue;
+      float row[VN];
+#pragma unroll
+      for (int k = 0; k < VN; ++k) row[k] = 0.f;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const Lerp lx = ge_lerp(ox, Wi, sx, align);
+        const float wx = (lx.i0 == X ? lx.w0 : 0.f) + (lx.i1 == X ? lx.w1 : 0.f);
+        if (wx == 0.f) continue;
+        float v[VN];
+        V8<T>::ld(g + ((long)oy * Wo + ox) * C, v);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) row[k] += wx * v[k];
+      }
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] += wy * row[k];
+    }
+    V8<T>::st(gin + ((n * Hi + Y) * (long)Wi + X) * C + c0, acc);
+  }
+}
+template <typename T>
+static int bilinear_nhwc_launch(bool fwd, const void* src, void* dst, int N, int C, int Hi, int Wi, int Ho, int Wo, int align, hipStream_t s) {
+  int lpr, rpi;
+  if (!nh_geom<T>(C, lpr, rpi) || !nh_aligned(src, dst)) return GE_ERR_UNSUPPORTED;
+  if (fwd) {
+    const long total = (long)N * Ho * Wo * lpr;
+    if (total == 0) return GE_OK;
+    bilinear_nhwc_fwd_k<T><<<ge_blocks(total, 256, 1 << 18), 256, 0, s>>>((const T*)src, (T*)dst, N, Hi, Wi, Ho, Wo, C, lpr, align);
+  } else {
+    const long total = (long)N * Hi * Wi * lpr;
+    if (total == 0) return GE_OK;
+    bilinear_nhwc_bwd_k<T><<<ge_blocks(total, 256, 1 << 18), 256, 0, s>>>((const T*)src, (T*)dst, N, Hi, Wi, Ho, Wo, C, lpr, align);
+  }
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+// in (N, Hi, Wi, C) -> out (N, Ho, Wo, C)
+extern "C" int ge_bilinear_nhwc_fwd(const void* in, void* out, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners, int dtype,
+                                    void* stream) {
+  if (!in || !out || N < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bilinear_nhwc_launch<float>(true, in, out, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
+  if (dtype == GE_BF16) return bilinear_nhwc_launch<bf16_t>(true, in, out, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+// d_out (N, Ho, Wo, C) -> d_in (N, Hi, Wi, C), fully written
+extern "C" int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners, int dtype,
+                                    void* stream) {
+  if (!d_out || !d_in || N < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bilinear_nhwc_launch<float>(false, d_out, d_in, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
+  if (dtype == GE_BF16) return bilinear_nhwc_launch<bf16_t>(false, d_out, d_in, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}
+
+// ================================================================================================= row concat / glue
+__device__ __forceinline__ float nh_drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {      // = ge_drop_scale (neck.hip)
+  uint32_t h = ((uint32_t)idx * 0x9E3779B1u) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u) ^ (uint32_t)seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  h += (uint32_t)(seed >> 32); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+  return ((float)(h >> 8) * (1.f / 16777216.f) >= p) ? inv_keep : 0.f;
+}
+// out[r, off_a : off_a + Ca] = a[r, :] * drop(r, c) + res[r, :]   (res may be NULL, p may be 0; `a` = B batches of rpb rows, batch
+//                                                                     stride a_bs elements: a token range of a longer sequence)
+// out[r, off_b : off_b + Cb] = b[r, :]                              (b may be NULL: only the first part is written)
+// rows of `out` have Ca + Cb elements; a, res, b are dense (R, Ca) / (R, Cb).
+template <typename T>
+__global__ void __launch_bounds__(256) concat_rows_k(const T* __restrict__ a, long rpb, long a_bs, const T* __restrict__ res, const T* __restrict__ b,
+                                                     T* __restrict__ out, long R, int Ca, int Cb, int off_a, int off_b, float p, float inv_keep,
+                                                     uint64_t seed) {
+  constexpr int VN = V8<T>::N;
+  const int la = Ca / VN, lb = b ? Cb / VN : 0, lt = la + lb, Co = Ca + Cb;
+  const long total = R * lt;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / lt;
+    const int j = (int)(i - r * lt);
+    float v[VN];
+    if (j < la) {
+      const int c0 = j * VN;
+      const long bi = r / rpb;
+      V8<T>::ld(a + bi * a_bs + (r - bi * rpb) * Ca + c0, v);                 // `a`: rows packed per batch, free batch stride
+      if (p > 0.f) {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v[k] *= nh_drop_scale(seed, (uint64_t)(r * Ca + c0 + k), p, inv_keep);
+      }
+      if (res) {
+        float q[VN];
+        V8<T>::ld(res + r * Ca + c0, q);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v[k] = Io<T>::rt(v[k]) + q[k];          // dropout(out) is materialised in T by the reference
+      }
+      V8<T>::st(out + r * Co + off_a + c0, v);
+    } else {
+      const int c0 = (j - la) * VN;
+      V8<T>::ld(b + r * Cb + c0, v);
+      V8<T>::st(out + r * Co + off_b + c0, v);
+    }
+  }
+}
+// backward of the first part: d_a[r, :] = d_out[r, off_a : off_a + Ca] * drop(r, c)  (dense (R, Ca) out of rows of Co)
+template <typename T>
+__global__ void __launch_bounds__(256) slice_rows_drop_k(const T* __restrict__ d_out, T* __restrict__ d_a, long R, int Ca, int Co, int off_a,
+                                                         float p, float inv_keep, uint64_t seed) {
+  constexpr int VN = V8<T>::N;
+  const int la = Ca / VN;
+  const long total = R * la;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / la;
+    const int c0 = (int)(i - r * la) * VN;
+    float v[VN];
+    V8<T>::ld(d_out + r * Co + off_a + c0, v);
+    if (p > 0.f) {
+#pragma unroll
+      for (int k = 0; k < VN; ++k) v[k] *= nh_drop_scale(seed, (uint64_t)(r * Ca + c0 + k), p, inv_keep);
+    }
+    V8<T>::st(d_a + r * Ca + c0, v);
+  }
+}
+extern "C" int ge_concat_rows_fwd(const void* a, long rows_per_batch, long a_batch_stride, const void* res, const void* b, void* out, long rows,
+                                  int Ca, int Cb, int a_first, float p_drop, unsigned long long seed, int dtype, void* stream) {
+  if (!a || !out || rows <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && !b) || p_drop < 0.f || p_drop >= 1.f) return GE_ERR_BAD_ARG;
+  if (rows_per_batch <= 0 || rows % rows_per_batch || a_batch_stride < rows_per_batch * Ca) return GE_ERR_BAD_ARG;
+  const int vn = dtype == GE_F32 ? 4 : 8;
+  if ((dtype != GE_F32 && dtype != GE_BF16) || Ca % vn || Cb % vn || a_batch_stride % vn || !nh_aligned(a, res, b, out)) return GE_ERR_UNSUPPORTED;
+  const int off_a = a_first ? 0 : Cb, off_b = a_first ? Ca : 0;
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const long total = rows * ((Ca + Cb) / vn);
+  hipStream_t s = ge_stream(stream);
+  if (dtype == GE_F32)
+    concat_rows_k<float><<<nh_grid_vec(total), 256, 0, s>>>((const float*)a, rows_per_batch, a_batch_stride, (const float*)res, Cb ? (const float*)b : nullptr, (float*)out, rows, Ca, Cb, off_a, off_b, p_drop, inv_keep, seed);
+  else
+    concat_rows_k<bf16_t><<<nh_grid_vec(total), 256, 0, s>>>((const bf16_t*)a, rows_per_batch, a_batch_stride, (const bf16_t*)res, Cb ? (const bf16_t*)b : nullptr, (bf16_t*)out, rows, Ca, Cb, off_a, off_b, p_drop, inv_keep, seed);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+extern "C" int ge_slice_rows_drop(const void* d_out, void* d_a, long rows, int Ca, int Co, int off_a, float p_drop, unsigned long long seed,
+                                  int dtype, void* stream) {
+  if (!d_out || !d_a || rows <= 0 || Ca <= 0 || Co < Ca || off_a < 0 || off_a + Ca > Co || p_drop < 0.f || p_drop >= 1.f) return GE_ERR_BAD_ARG;
+  const int vn = dtype == GE_F32 ? 4 : 8;
+  if ((dtype != GE_F32 && dtype != GE_BF16) || Ca % vn || Co % vn || off_a % vn || !nh_aligned(d_out, d_a)) return GE_ERR_UNSUPPORTED;
+  const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  hipStream_t s = ge_stream(stream);
+  if (dtype == GE_F32)
+    slice_rows_drop_k<float><<<nh_grid_vec(rows * (Ca / vn)), 256, 0, s>>>((const float*)d_out, (float*)d_a, rows, Ca, Co, off_a, p_drop, inv_keep, seed);
+  else
+    slice_rows_drop_k<bf16_t><<<nh_grid_vec(rows * (Ca / vn)), 256, 0, s>>>((const bf16_t*)d_out, (bf16_t*)d_a, rows, Ca, Co, off_a, p_drop, inv_keep, seed);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+// tokens + positional embedding: out[b, n, :] = x[b, n, :] + pos[n, :] (pos fp32 (N, C), one rounding into T)
+template <typename T>
+__global__ void __launch_bounds__(256) add_rows_k(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ out, long per_batch_vec,
+                                                  long total_vec) {
+  constexpr int VN = V8<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long)gridDim.x * 256) {
+    const long j = i % per_batch_vec;
+    float v[VN];
+    V8<T>::ld(x + i * VN, v);
+#pragma unroll
+    for (int k = 0; k < VN; k += 4) {
+      const float4 q = *(const float4*)(pos + j * VN + k);
+      v[k] += q.x; v[k + 1] += q.y; v[k + 2] += q.z; v[k + 3] += q.w;
+    }
+    V8<T>::st(out + i * VN, v);
+  }
+}
+extern "C" int ge_add_rows(const void* x, const float* pos, void* out, int B, long N, int C, int dtype, void* stream) {
+  if (!x || !pos || !out || B <= 0 || N <= 0 || C <= 0) return GE_ERR_BAD_ARG;
+  const int vn = dtype == GE_F32 ? 4 : 8;
+  if ((dtype != GE_F32 && dtype != GE_BF16) || C % vn || !nh_aligned(x, pos, out)) return GE_ERR_UNSUPPORTED;
+  const long per = N * C / vn, total = per * B;
+  hipStream_t s = ge_stream(stream);
+  if (dtype == GE_F32) add_rows_k<float><<<nh_grid_vec(total), 256, 0, s>>>((const float*)x, pos, (float*)out, per, total);
+  else add_rows_k<bf16_t><<<nh_grid_vec(total), 256, 0, s>>>((const bf16_t*)x, pos, (bf16_t*)out, per, total);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}

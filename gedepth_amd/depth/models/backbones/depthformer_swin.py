@@ -257,8 +257,12 @@ class DepthFormerSwin(BaseModule):
         self.load_state_dict(state, strict=False)
 
     # ------------------------------------------------------------------ forward
+    channels_last = False       # set by depth.models.utils.to_channels_last: maps leave / enter the backbone as (B, H, W, C) storage
+
     def conv_stem(self, x):
         bn = getattr(self, self._stem_norm_name)
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
         y = self.conv1(x)
         if (y.is_cuda and type(bn) is nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats
                 and bn.momentum is not None):
@@ -268,7 +272,10 @@ class DepthFormerSwin(BaseModule):
 
     def forward(self, x_ori):
         outs = [self.conv_stem(x_ori[:, 0:3] if self.USEPE else x_ori)]
-        x, hw_shape = self.patch_embed(x_ori[:, 0:4] if self.USEPE else x_ori)
+        x4 = x_ori[:, 0:4] if self.USEPE else x_ori
+        if self.channels_last:                        # the k4 s4 projection then emits (B, H/4, W/4, C): tokens without a transpose
+            x4 = x4.contiguous(memory_format=torch.channels_last)
+        x, hw_shape = self.patch_embed(x4)
         if self.use_abs_pos_embed:
             x = x + self.absolute_pos_embed
         x = self.drop_after_pos(x)
@@ -276,5 +283,6 @@ class DepthFormerSwin(BaseModule):
             x, hw_shape, out, out_hw = stage(x, hw_shape)
             if i in self.out_indices:
                 out = getattr(self, f'norm{i}')(out)
-                outs.append(out.view(-1, *out_hw, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+                out = out.view(-1, *out_hw, self.num_features[i]).permute(0, 3, 1, 2)     # channels-last storage of a (B,C,H,W) map
+                outs.append(out if self.channels_last else out.contiguous())
         return outs

@@ -54,6 +54,15 @@ SIGNATURES = {
     'ge_slope_class': (_i, [_vp, _vp, _d, _i, _vp, _i, _i, _vp]),
     'ge_slope_class_ddad': (_i, [_vp, _vp, _d, _vp, _i, _i, _vp]),
     'ge_pe_channels': (_i, [_vp, _vp, _f, _l, _vp]),
+    'ge_bn_act_nhwc_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _f, _i, _vp]),
+    'ge_bn_act_nhwc_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
+    'ge_bias_act_nhwc_fwd': (_i, [_vp, _vp, _l, _i, _f, _i, _vp]),
+    'ge_bias_act_nhwc_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
+    'ge_bilinear_nhwc_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_bilinear_nhwc_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_concat_rows_fwd': (_i, [_vp, _l, _l, _vp, _vp, _vp, _l, _i, _i, _i, _f, _u64, _i, _vp]),
+    'ge_slice_rows_drop': (_i, [_vp, _vp, _l, _i, _i, _i, _f, _u64, _i, _vp]),
+    'ge_add_rows': (_i, [_vp, _vp, _vp, _i, _l, _i, _i, _vp]),
     'ge_aug_load': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_depth': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_resize': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

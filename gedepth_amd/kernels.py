@@ -259,6 +259,31 @@ def msda_prepare(raw, reference_points, spatial_shapes, num_heads, num_levels, n
     return _MSDAPrep.apply(raw, reference_points, spatial_shapes, num_heads, num_levels, num_points)
 
 
+# ---------------------------------------------------------------------------- channels-last helpers
+_CL = torch.channels_last
+
+
+def _is_cl(x):
+    """A 4-D map stored channels-last (B, H, W, C) with C > 1 — i.e. the row matrix (B*H*W, C) the NHWC kernels take."""
+    return x.dim() == 4 and x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=_CL)
+
+
+def _cl_ok(x):
+    """NHWC kernels apply: channels-last storage, C a multiple of the 16-byte vector and <= 2048."""
+    vn = 8 if x.dtype == torch.bfloat16 else 4
+    return x.is_cuda and _is_cl(x) and x.shape[1] % vn == 0 and x.shape[1] <= 2048 and x.dtype in (_f32, torch.bfloat16)
+
+
+def _cl(x):
+    return x if _is_cl(x) else x.contiguous(memory_format=_CL)
+
+
+def _rows_of(x):
+    """(rows, C) of a channels-last map"""
+    B, C, H, W = x.shape
+    return B * H * W, C
+
+
 # ------------------------------------------------------------------- feature map <-> token sequence
 def _planes(x):
     """(B,C,H,W) with contiguous (H,W) planes packed over C; the batch stride is free (channel slices of a concat)."""
@@ -311,8 +336,44 @@ class _TokensFromMap(torch.autograd.Function):
         return d_map, None
 
 
+class _AddRows(torch.autograd.Function):
+    """tokens (B,N,C) + pos (N,C) fp32, one pass, one rounding (channels-last path of ``tokens_from_map``)."""
+
+    @staticmethod
+    def forward(ctx, tok, pos_rows):
+        tok = _c(tok)
+        B, N, C = tok.shape
+        out = torch.empty_like(tok)
+        PROFILER.run(f'add_rows[{B}x{N}x{C} {_tag(tok)}]', 2 * tok.numel() * _es(tok) + N * C * 4, lambda: hip.check(
+            hip.lib().ge_add_rows(hip.ptr(tok, name='tokens'), hip.ptr(pos_rows, _f32), hip.ptr(out), B, N, C, hip.dtype_code(tok),
+                                  hip.stream()), 'ge_add_rows'))
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, None
+
+
+_POS_ROWS = {}
+
+
+def _pos_rows(pos):
+    """(1,C,H,W) cached positional map -> (H*W, C) fp32 rows, cached per source tensor."""
+    key = (pos.data_ptr(), tuple(pos.shape))
+    if key not in _POS_ROWS:
+        if len(_POS_ROWS) > 64:
+            _POS_ROWS.clear()
+        _POS_ROWS[key] = pos.detach().to(_f32).flatten(2)[0].t().contiguous()
+    return _POS_ROWS[key]
+
+
 def tokens_from_map(fmap, pos=None):
-    """(B,C,H,W) [+ pos (1,C,H,W) fp32] -> (B,H*W,C): ``fmap.flatten(2).transpose(1,2) + pos`` in one transposing pass."""
+    """(B,C,H,W) [+ pos (1,C,H,W) fp32] -> (B,H*W,C): ``fmap.flatten(2).transpose(1,2) + pos`` in one transposing pass;
+    for a channels-last map the token matrix is a VIEW of it and only the position add is a kernel."""
+    if _cl_ok(fmap):
+        B, C, H, W = fmap.shape
+        tok = fmap.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        return tok if pos is None else _AddRows.apply(tok, _pos_rows(pos))
     return _TokensFromMap.apply(fmap, pos)
 
 
@@ -354,12 +415,51 @@ class _ConcatTokensMap(torch.autograd.Function):
         return d_tok, d_out[:, m0:m0 + Cm], (d_slice if has_id else None), None, None, None
 
 
+class _ConcatRows(torch.autograd.Function):
+    """Channels-last ``concat_tokens_map``: rows of [dropout(tokens) + identity | fmap] written once (csrc/nhwc.hip)."""
+
+    @staticmethod
+    def forward(ctx, tok, fmap, identity, tokens_first, p, seed):
+        tok = _rows(tok)
+        B, N, C = tok.shape
+        _, Cm, H, W = fmap.shape
+        assert H * W == N and fmap.shape[0] == B
+        fmap = _cl(fmap)
+        res = None if identity is None else _cl(identity.to(tok.dtype))
+        out = torch.empty((B, C + Cm, H, W), device=tok.device, dtype=tok.dtype, memory_format=_CL)
+        PROFILER.run(f'concat_rows[{B}x{N}x({C}+{Cm}) {_tag(tok)}{" +res" if res is not None else ""}{" drop" if p > 0 else ""}]',
+                     ((2 + (res is not None)) * tok.numel() + 2 * fmap.numel()) * _es(tok), lambda: hip.check(hip.lib().ge_concat_rows_fwd(
+                         _raw_ptr(tok, 'tokens'), N, tok.stride(0), None if res is None else _raw_ptr(res, 'identity'), _raw_ptr(fmap, 'map'),
+                         _raw_ptr(out, 'out'), B * N, C, Cm, int(tokens_first), p, seed, hip.dtype_code(tok), hip.stream()), 'ge_concat_rows_fwd'))
+        ctx.meta = (B, N, C, Cm, tokens_first, p, seed, identity is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, N, C, Cm, tokens_first, p, seed, has_id = ctx.meta
+        d_out = _cl(d_out)
+        t0, m0 = (0, C) if tokens_first else (Cm, 0)
+        d_slice = d_out[:, t0:t0 + C]
+        if p > 0:
+            d_tok = torch.empty(B, N, C, device=d_out.device, dtype=d_out.dtype)
+            PROFILER.run(f'slice_rows_drop[{B}x{N}x{C} {_tag(d_out)}]', 2 * d_tok.numel() * _es(d_out), lambda: hip.check(
+                hip.lib().ge_slice_rows_drop(_raw_ptr(d_out, 'd_out'), hip.ptr(d_tok), B * N, C, C + Cm, t0, p, seed, hip.dtype_code(d_out),
+                                             hip.stream()), 'ge_slice_rows_drop'))
+        else:
+            d_tok = d_slice.permute(0, 2, 3, 1).reshape(B, N, C)               # a strided view: the consumer packs it
+        return d_tok, d_out[:, m0:m0 + Cm], (d_slice if has_id else None), None, None, None
+
+
 def concat_tokens_map(tokens, fmap, identity=None, tokens_first=True, p_drop=0.0, seed=None):
     """``torch.cat([to_map(dropout(tokens)) + identity, fmap], 1)`` (or fmap first) with the token part transposed,
     dropped and added straight into the concat buffer.  tokens (B,H*W,C), fmap (B,Cm,H,W), identity (B,C,H,W)."""
     p_drop = float(p_drop)
     if p_drop > 0.0 and seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # host generator: follows torch.manual_seed, no device sync
+    vn = 8 if tokens.dtype == torch.bfloat16 else 4
+    if (_cl_ok(fmap) and tokens.shape[2] % vn == 0 and tokens.is_cuda and tokens.dtype == fmap.dtype and tokens.stride(2) == 1
+            and tokens.stride(1) == tokens.shape[2] and tokens.stride(0) % vn == 0):
+        return _ConcatRows.apply(tokens, fmap, identity, bool(tokens_first), p_drop, int(seed or 0))
     return _ConcatTokensMap.apply(tokens, fmap, identity, bool(tokens_first), p_drop, int(seed or 0))
 
 
@@ -368,18 +468,32 @@ class _Bilinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, Ho, Wo, align_corners):
-        x = _c(x)
         N, C, Hi, Wi = x.shape
+        ctx.cl = _cl_ok(x)
+        ctx.geom = (N, C, Hi, Wi, Ho, Wo, int(align_corners))
+        if ctx.cl:
+            out = torch.empty((N, C, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=_CL)
+            PROFILER.run(f'bilinear_nhwc_fwd[{N}x{C} {Hi}x{Wi}->{Ho}x{Wo} {_tag(x)}]', (x.numel() + out.numel()) * _es(x), lambda: hip.check(
+                hip.lib().ge_bilinear_nhwc_fwd(_raw_ptr(x, 'input'), _raw_ptr(out, 'out'), N, C, Hi, Wi, Ho, Wo, int(align_corners),
+                                               hip.dtype_code(x), hip.stream()), 'ge_bilinear_nhwc_fwd'))
+            return out
+        x = _c(x)
         out = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
         PROFILER.run(f'bilinear_fwd[{N}x{C} {Hi}x{Wi}->{Ho}x{Wo} {_tag(x)}]', (x.numel() + out.numel()) * _es(x), lambda: hip.check(
             hip.lib().ge_bilinear_fwd(hip.ptr(x, name='input'), hip.ptr(out), N, C, Hi, Wi, Ho, Wo, int(align_corners),
                                       hip.dtype_code(x), hip.stream()), 'ge_bilinear_fwd'))
-        ctx.geom = (N, C, Hi, Wi, Ho, Wo, int(align_corners))
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         N, C, Hi, Wi, Ho, Wo, ac = ctx.geom
+        if ctx.cl:
+            d_out = _cl(d_out)
+            d_in = torch.empty((N, C, Hi, Wi), device=d_out.device, dtype=d_out.dtype, memory_format=_CL)
+            PROFILER.run(f'bilinear_nhwc_bwd[{N}x{C} {Hi}x{Wi}<-{Ho}x{Wo} {_tag(d_out)}]', (d_out.numel() + d_in.numel()) * _es(d_out),
+                         lambda: hip.check(hip.lib().ge_bilinear_nhwc_bwd(_raw_ptr(d_out, 'd_out'), _raw_ptr(d_in, 'd_in'), N, C, Hi, Wi, Ho, Wo, ac,
+                                                                          hip.dtype_code(d_out), hip.stream()), 'ge_bilinear_nhwc_bwd'))
+            return d_in, None, None, None
         d_out = _c(d_out)
         d_in = torch.empty(N, C, Hi, Wi, device=d_out.device, dtype=d_out.dtype)
         PROFILER.run(f'bilinear_bwd[{N}x{C} {Hi}x{Wi}<-{Ho}x{Wo} {_tag(d_out)}]', (d_out.numel() + d_in.numel()) * _es(d_out),
@@ -478,12 +592,22 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, slope):
-        x = _c(x)
+        ctx.cl = _cl_ok(x)
+        if not ctx.cl:
+            x = _c(x)
         N, C, H, W = x.shape
         w, b = _c(weight.detach().to(_f32)), _c(bias.detach().to(_f32))
-        y = torch.empty_like(x)
+        y = torch.empty_like(x)                                  # preserves the channels-last strides
         stats = torch.empty(2, C, device=x.device, dtype=_f32)
         ws = torch.empty(int(hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
+        if ctx.cl:
+            PROFILER.run(f'bn_act_nhwc_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 3 * x.numel() * _es(x), lambda: hip.check(
+                hip.lib().ge_bn_act_nhwc_fwd(_raw_ptr(x, 'x'), hip.ptr(w), hip.ptr(b), _raw_ptr(y, 'y'), hip.ptr(stats[0]), hip.ptr(stats[1]),
+                                             hip.ptr(running_mean, _f32), hip.ptr(running_var, _f32), hip.ptr(ws), N * H * W, C, eps,
+                                             momentum, slope, hip.dtype_code(x), hip.stream()), 'ge_bn_act_nhwc_fwd'))
+            ctx.save_for_backward(x, y, w, stats)
+            ctx.slope = slope
+            return y
         PROFILER.run(f'bn_act_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 3 * x.numel() * _es(x), lambda: hip.check(
             hip.lib().ge_bn_act_fwd(hip.ptr(x, name='x'), hip.ptr(w), hip.ptr(b), hip.ptr(y), hip.ptr(stats[0]), hip.ptr(stats[1]),
                                     hip.ptr(running_mean, _f32), hip.ptr(running_var, _f32), hip.ptr(ws), N, C, H * W, eps,
@@ -496,10 +620,17 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, w, stats = ctx.saved_tensors
         N, C, H, W = x.shape
-        dy = _c(dy.to(x.dtype))
         dx = torch.empty_like(x)
         dwb = torch.empty(2, C, device=x.device, dtype=_f32)
         ws = torch.empty(int(hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
+        if ctx.cl:
+            dy = _cl(dy.to(x.dtype))
+            PROFILER.run(f'bn_act_nhwc_bwd[{N}x{C}x{H}x{W} {_tag(x)}]', 7 * x.numel() * _es(x), lambda: hip.check(
+                hip.lib().ge_bn_act_nhwc_bwd(_raw_ptr(dy, 'dy'), _raw_ptr(y, 'y'), _raw_ptr(x, 'x'), hip.ptr(w), hip.ptr(stats[0]), hip.ptr(stats[1]),
+                                             _raw_ptr(dx, 'dx'), hip.ptr(dwb[0]), hip.ptr(dwb[1]), hip.ptr(ws), N * H * W, C, ctx.slope,
+                                             hip.dtype_code(x), hip.stream()), 'ge_bn_act_nhwc_bwd'))
+            return dx, dwb[0], dwb[1], None, None, None, None, None
+        dy = _c(dy.to(x.dtype))
         PROFILER.run(f'bn_act_bwd[{N}x{C}x{H}x{W} {_tag(x)}]', 7 * x.numel() * _es(x), lambda: hip.check(
             hip.lib().ge_bn_act_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(x), hip.ptr(w), hip.ptr(stats[0]), hip.ptr(stats[1]), hip.ptr(dx),
                                     hip.ptr(dwb[0]), hip.ptr(dwb[1]), hip.ptr(ws), N, C, H * W, ctx.slope, hip.dtype_code(x),
@@ -520,9 +651,18 @@ class _BiasAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, slope):
-        assert x.dim() == 4 and x.is_contiguous(), 'bias_act works in place on a contiguous NCHW conv output'
+        ctx.cl = _cl_ok(x)
+        assert x.dim() == 4 and (x.is_contiguous() or ctx.cl), 'bias_act works in place on a dense NCHW / channels-last conv output'
         N, C, H, W = x.shape
         b = _c(bias.detach().to(_f32))
+        if ctx.cl:
+            PROFILER.run(f'bias_act_nhwc_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 2 * x.numel() * _es(x), lambda: hip.check(
+                hip.lib().ge_bias_act_nhwc_fwd(_raw_ptr(x, 'x'), hip.ptr(b), N * H * W, C, slope, hip.dtype_code(x), hip.stream()),
+                'ge_bias_act_nhwc_fwd'))
+            ctx.mark_dirty(x)
+            ctx.save_for_backward(x)
+            ctx.slope = slope
+            return x
         PROFILER.run(f'bias_act_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 2 * x.numel() * _es(x), lambda: hip.check(
             hip.lib().ge_bias_act_fwd(hip.ptr(x, name='x'), hip.ptr(b), N, C, H * W, slope, hip.dtype_code(x), hip.stream()),
             'ge_bias_act_fwd'))
@@ -535,8 +675,16 @@ class _BiasAct(torch.autograd.Function):
     def backward(ctx, dy):
         y, = ctx.saved_tensors
         N, C, H, W = y.shape
-        dy = _c(dy.to(y.dtype))
         dx = torch.empty_like(y)
+        if ctx.cl:
+            dy = _cl(dy.to(y.dtype))
+            db = torch.empty(C, device=y.device, dtype=_f32)
+            ws = torch.empty(C, device=y.device, dtype=torch.float64)
+            PROFILER.run(f'bias_act_nhwc_bwd[{N}x{C}x{H}x{W} {_tag(y)}]', 3 * y.numel() * _es(y), lambda: hip.check(
+                hip.lib().ge_bias_act_nhwc_bwd(_raw_ptr(dy, 'dy'), _raw_ptr(y, 'y'), _raw_ptr(dx, 'dx'), hip.ptr(db), hip.ptr(ws), N * H * W, C,
+                                               ctx.slope, hip.dtype_code(y), hip.stream()), 'ge_bias_act_nhwc_bwd'))
+            return dx, db, None
+        dy = _c(dy.to(y.dtype))
         db = torch.zeros(C, device=y.device, dtype=_f32)
         PROFILER.run(f'bias_act_bwd[{N}x{C}x{H}x{W} {_tag(y)}]', 3 * y.numel() * _es(y), lambda: hip.check(
             hip.lib().ge_bias_act_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(dx), hip.ptr(db), N, C, H * W, ctx.slope,

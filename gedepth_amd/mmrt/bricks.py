@@ -328,7 +328,7 @@ def conv_bias_act(conv, x, slope=1.0):
     and an activation kernel, and two more for their gradients)."""
     from .. import kernels
     y = conv._conv_forward(x, conv.weight, None)
-    if not y.is_contiguous():
+    if not (y.is_contiguous() or kernels._cl_ok(y)):           # dense NCHW or (vector-sized) channels-last both run in place
         y = y.contiguous()
     return kernels.bias_act_(y, conv.bias, slope)
 

@@ -32,10 +32,20 @@ class GradArena:
         self.flat_param = torch.zeros(n, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
         for p, off in zip(self.params, self.offsets):
-            view = self.flat_param[off:off + p.numel()].view_as(p)
+            view = self._view(self.flat_param, off, p)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            p.grad = self._view(self.flat_grad, off, p)
+
+    @staticmethod
+    def _view(flat, off, p):
+        """A view of the arena slice shaped (and, for channels-last conv weights, strided) like ``p``: the optimizer is
+        element-wise, so the storage order inside a slice is free and convolution weights can stay in MIOpen's NHWC order."""
+        chunk = flat[off:off + p.numel()]
+        if p.dim() == 4 and p.shape[1] > 1 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            O, I, H, W = p.shape
+            return chunk.view(O, H, W, I).permute(0, 3, 1, 2)
+        return chunk.view_as(p)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -43,7 +53,7 @@ class GradArena:
     def reattach(self):
         """Copy externally-assigned ``.grad`` tensors into the arena and re-point them (tests / foreign code)."""
         for p, off in zip(self.params, self.offsets):
-            view = self.flat_grad[off:off + p.numel()].view_as(p)
+            view = self._view(self.flat_grad, off, p)
             if p.grad is None:
                 view.zero_()
             elif p.grad.data_ptr() != view.data_ptr():
@@ -127,8 +137,8 @@ class FusedAdamW(torch.optim.Optimizer):
         state = {}
         for p, (off, n) in zip(self.arena.params, self.arena.slices()):
             state[index[id(p)]] = dict(step=torch.tensor(float(self.step_count)),
-                                       exp_avg=self.exp_avg[off:off + n].view_as(p).clone(),
-                                       exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p).clone())
+                                       exp_avg=GradArena._view(self.exp_avg, off, p).clone(),
+                                       exp_avg_sq=GradArena._view(self.exp_avg_sq, off, p).clone())
         groups = []
         for g in self.param_groups:
             d = {k: v for k, v in g.items() if k != 'params'}
@@ -164,21 +174,22 @@ class FusedAdamW(torch.optim.Optimizer):
         for p, (off, n) in zip(self.arena.params, self.arena.slices()):
             rec = st.get(id_of[id(p)])
             if rec is None:                                              # parameter that never received a gradient
-                plan.append((off, n, None))
+                plan.append((off, p, None))
                 continue
             for k in ('exp_avg', 'exp_avg_sq'):
                 if tuple(rec[k].shape) != tuple(p.shape):
                     raise ValueError(f'optimizer state {k} of parameter {id_of[id(p)]}: shape {tuple(rec[k].shape)} != {tuple(p.shape)}')
             steps.add(int(float(rec['step'])))
-            plan.append((off, n, rec))
+            plan.append((off, p, rec))
         if len(steps) > 1:
             raise NotImplementedError(f'FusedAdamW keeps one step counter; the checkpoint has {sorted(steps)}')
-        for off, n, rec in plan:
+        for off, p, rec in plan:
             for buf, k in ((self.exp_avg, 'exp_avg'), (self.exp_avg_sq, 'exp_avg_sq')):
+                view = GradArena._view(buf, off, p)                         # same element order as the parameter's arena slice
                 if rec is None:
-                    buf[off:off + n].zero_()
+                    view.zero_()
                 else:
-                    buf[off:off + n].copy_(rec[k].reshape(-1).to(buf.device, torch.float32))
+                    view.copy_(rec[k].to(buf.device, torch.float32))
         self.step_count = steps.pop() if steps else 0
         for g, s in zip(self.param_groups, saved_groups):
             g.update({k: v for k, v in s.items() if k != 'params'})

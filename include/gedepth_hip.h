@@ -268,6 +268,40 @@ int ge_slope_class_ddad(const float* gt, const double* pe, double cam_height, in
 int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Channels-last (NHWC) variants of the map kernels (csrc/nhwc.hip).  A channels-last map (B, C, H, W) with strides
+ * (HWC, 1, WC, C) is the row matrix (rows = B*H*W, C): MIOpen's bf16 implicit-GEMM convolutions run on it without their
+ * NCHW <-> NHWC batched_transpose kernels, and tokens <-> maps become views.  C must be a multiple of the 16-byte vector
+ * (8 bf16 / 4 f32) and <= 2048, pointers 16-byte aligned; otherwise GE_ERR_UNSUPPORTED (the caller keeps NCHW).
+ * ge_bn_act_nhwc_*: as ge_bn_act_* (same workspace size, ge_bn_workspace(C)); statistics are column sums.
+ * ge_bias_act_nhwc_*: as ge_bias_act_*; the backward needs a workspace of C doubles, d_bias is fully written.
+ * ge_bilinear_nhwc_*: as ge_bilinear_* on (N, H, W, C).
+ * ge_concat_rows_fwd: out (rows, Ca+Cb) = [a * dropout + res | b] (a first) or [b | a * dropout + res]; `a` is B batches
+ *   of rows_per_batch packed rows with a free batch stride (a token range of a longer sequence), res / b / out dense:
+ *   torch.cat([to_map(dropout(tokens)) + identity, fmap], 1) of necks/hahi.py:326-346 on channels-last maps.
+ * ge_slice_rows_drop: its backward w.r.t. a: d_a (rows, Ca) = d_out[:, off_a : off_a + Ca] * dropout.
+ * ge_add_rows: out (B, N, C) = x + pos (N, C) f32 broadcast over the batch (query + query_pos, hahi.py:303-306).
+ */
+int ge_bn_act_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                       float* running_mean, float* running_var, void* workspace, long rows, int C, float eps,
+                       float momentum, float slope, int dtype, void* stream);
+int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+                       const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, long rows, int C,
+                       float slope, int dtype, void* stream);
+int ge_bias_act_nhwc_fwd(void* x, const float* bias, long rows, int C, float slope, int dtype, void* stream);
+int ge_bias_act_nhwc_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, long rows, int C,
+                         float slope, int dtype, void* stream);
+int ge_bilinear_nhwc_fwd(const void* in, void* out, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
+                         int dtype, void* stream);
+int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
+                         int dtype, void* stream);
+int ge_concat_rows_fwd(const void* a, long rows_per_batch, long a_batch_stride, const void* res, const void* b, void* out,
+                       long rows, int Ca, int Cb, int a_first, float p_drop, unsigned long long seed, int dtype,
+                       void* stream);
+int ge_slice_rows_drop(const void* d_out, void* d_a, long rows, int Ca, int Co, int off_a, float p_drop,
+                       unsigned long long seed, int dtype, void* stream);
+int ge_add_rows(const void* x, const float* pos, void* out, int B, long N, int C, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Device-side data pipeline of the training samples (csrc/aug.hip).  Planar f32 maps (C, H, W); each
  * entry point restates one host transform of the reference's KITTI train pipeline
  * (configs/depthformer/depthformer_v.py:13-28 -> depth/datasets/pipelines/transforms.py / loading.py), applied with the

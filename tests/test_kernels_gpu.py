@@ -1065,3 +1065,112 @@ def test_ground_plane_and_slope_classes_vs_reference_scripts(dev, golden):
         assert np.array_equal(pe64.cpu().numpy(), ref)
         k = slope_class_ddad(torch.from_numpy(g[f'ddad{i}_gt']).to(dev), pe64, pp_ddad.CAMERA_HEIGHTS[cam]).cpu().numpy()
         assert np.array_equal(k.astype(np.int64), g[f'ddad{i}_k']), int((k != g[f'ddad{i}_k']).sum())
+
+
+# ===================================================================== channels-last (NHWC) kernel variants
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('geom', [(2, 64, 12, 20), (3, 96, 7, 9), (2, 512, 4, 6), (1, 1536, 2, 3), (2, 8, 33, 17)])
+def test_nhwc_bn_act_bias_act_bilinear_match_nchw(dev, dtype, geom):
+    """csrc/nhwc.hip against the NCHW kernels of the same ops (which are pinned to ATen / the oracle above): training-mode
+    BatchNorm + ReLU (column statistics), conv bias + LeakyReLU (bias gradient = column sums), bilinear resize both ways;
+    forward, every gradient and the running statistics, on the same values stored channels-last."""
+    from gedepth_amd import kernels
+    from gedepth_amd.kernels import bias_act_, bilinear_resize, bn_act
+    B, C, H, W = geom
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = gen(B * 100 + C + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 2 + 0.3).to(td)
+    go = torch.randn(B, C, H, W, generator=g).to(td)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == 'bf16' else dict(rtol=1e-4, atol=1e-5)
+
+    def bn_run(cl):
+        bn = torch.nn.BatchNorm2d(C).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.3, 0.3, C))
+        xi = x.to(dev)
+        xi = (_cl(xi) if cl else xi).requires_grad_(True)
+        assert kernels._cl_ok(xi) == cl
+        y = bn_act(xi, bn, 0.0)
+        assert kernels._is_cl(y) == cl
+        y.backward(_cl(go.to(dev)) if cl else go.to(dev))
+        return [t.float().cpu() for t in (y, xi.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)]
+    for a, b, n in zip(bn_run(True), bn_run(False), ('y', 'dx', 'dgamma', 'dbeta', 'running_mean', 'running_var')):
+        if n in ('dgamma', 'dbeta'):
+            close_scaled(a, b, rel=2e-2 if dtype == 'bf16' else 1e-4, what=f'bn_act nhwc {n}')
+        else:
+            close(a, b, what=f'bn_act nhwc {n}', **tol)
+
+    def bias_run(cl):
+        bias = torch.linspace(-1, 1, C, device=dev).requires_grad_(True)
+        xi = x.to(dev)
+        xi = (_cl(xi) if cl else xi).requires_grad_(True)
+        y = bias_act_(xi * 1.0, bias, 0.01)
+        assert kernels._is_cl(y) == cl
+        y.backward(_cl(go.to(dev)) if cl else go.to(dev))
+        return [t.float().cpu() for t in (y, xi.grad, bias.grad)]
+    for a, b, n in zip(bias_run(True), bias_run(False), ('y', 'dx', 'dbias')):
+        (close_scaled(a, b, rel=2e-2 if dtype == 'bf16' else 1e-4, what=f'bias_act nhwc {n}') if n == 'dbias'
+         else close(a, b, what=f'bias_act nhwc {n}', **tol))
+
+    for size, align in (((2 * H, 2 * W), True), ((2 * H, 2 * W), False), ((max(1, H // 2), max(1, W // 2)), True), ((3 * H + 1, 2 * W - 1), False)):
+        def bil_run(cl):
+            xi = x.to(dev)
+            xi = (_cl(xi) if cl else xi).requires_grad_(True)
+            y = bilinear_resize(xi, size, align)
+            assert kernels._is_cl(y) == cl
+            gy = torch.randn(y.shape, generator=gen(5)).to(td).to(dev)
+            y.backward(_cl(gy) if cl else gy)
+            return y.float().cpu(), xi.grad.float().cpu()
+        (ya, ga), (yb, gb) = bil_run(True), bil_run(False)
+        close(ya, yb, what=f'bilinear nhwc fwd {size} ac={align}', **tol)
+        close_scaled(ga, gb, rel=2e-2 if dtype == 'bf16' else 1e-4, what=f'bilinear nhwc bwd {size} ac={align}')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('tokens_first', [True, False])
+def test_nhwc_token_map_glue_matches_nchw(dev, dtype, tokens_first):
+    """tokens_from_map (a view + the position add) and concat_tokens_map (row concatenation with dropout-free residual) on
+    channels-last maps against the transposing NCHW kernels; with dropout the two paths draw different masks, so that case
+    checks the statistics and the forward / backward mask consistency instead."""
+    from gedepth_amd import kernels
+    from gedepth_amd.kernels import concat_tokens_map, tokens_from_map
+    B, C, Cm, H, W = 2, 64, 24, 6, 10
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    g = gen(31)
+    fmap = torch.randn(B, C, H, W, generator=g).to(td)
+    pos = torch.randn(1, C, H, W, generator=g)
+    tokens = torch.randn(B, 3 * H * W, C, generator=g).to(td)[:, H * W:2 * H * W]      # a token range of a longer sequence
+    skip = torch.randn(B, Cm, H, W, generator=g).to(td)
+    go_t = torch.randn(B, H * W, C, generator=g).to(td)
+    go_m = torch.randn(B, C + Cm, H, W, generator=g).to(td)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == 'bf16' else dict(rtol=1e-5, atol=1e-6)
+
+    def run(cl):
+        f = fmap.to(dev)
+        f = (_cl(f) if cl else f).requires_grad_(True)
+        t = tokens_from_map(f, pos.to(dev))
+        t.backward(go_t.to(dev))
+        tk = tokens.to(dev).requires_grad_(True)                       # batch-strided rows
+        sk = skip.to(dev)
+        sk = (_cl(sk) if cl else sk).requires_grad_(True)
+        idt = fmap.to(dev)
+        idt = (_cl(idt) if cl else idt).requires_grad_(True)
+        out = concat_tokens_map(tk, sk, identity=idt, tokens_first=tokens_first, p_drop=0.0)
+        assert kernels._is_cl(out) == cl
+        out.backward(_cl(go_m.to(dev)) if cl else go_m.to(dev))
+        return [v.float().cpu() for v in (t, f.grad, out, tk.grad, sk.grad, idt.grad)]
+    for a, b, n in zip(run(True), run(False), ('tokens', 'd map', 'concat', 'd tokens', 'd skip', 'd identity')):
+        close(a, b, what=f'nhwc glue {n}', **tol)
+    # dropout: E[out] preserved, dropped positions get zero gradient, kept ones 1 / (1 - p)
+    tk = torch.ones(B, H * W, C, device=dev, dtype=td, requires_grad=True)
+    sk = _cl(torch.zeros(B, Cm, H, W, device=dev, dtype=td))
+    out = concat_tokens_map(tk, sk, tokens_first=tokens_first, p_drop=0.25, seed=1234)
+    part = out[:, :C] if tokens_first else out[:, Cm:]
+    vals = part.float().unique().tolist()
+    assert set(round(v, 3) for v in vals) <= {0.0, round(1 / 0.75, 3)} and abs(part.float().mean().item() - 1.0) < 0.05
+    out.sum().backward()
+    assert torch.equal((tk.grad.float() > 0), (part.permute(0, 2, 3, 1).reshape(B, H * W, C).float() > 0))

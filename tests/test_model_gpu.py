@@ -339,3 +339,39 @@ def test_rccl_gradient_exchange_single_rank(dev):
     if r.returncode != 0 or 'RCCL_DDP_OK' not in r.stdout:
         print('---- worker stdout ----\n' + r.stdout[-6000:] + '\n---- worker stderr ----\n' + r.stderr[-6000:])
     assert r.returncode == 0 and 'RCCL_DDP_OK' in r.stdout
+
+
+@pytest.mark.parametrize('amp', [False, True])
+def test_channels_last_model_matches_nchw(dev, amp):
+    """depth.models.utils.to_channels_last: the same parameters, the same input -> the same losses and gradients as the NCHW
+    execution (fp32: to accumulation order; bf16 autocast: to bf16 rounding), with the maps really flowing channels-last."""
+    from gedepth_amd import kernels
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.depth.models.utils import to_channels_last
+    batch = synthetic_batch(2, 128, 160, seed=9, device=dev, valid_fraction=0.3)
+    res = {}
+    for layout in ('nchw', 'nhwc'):
+        torch.manual_seed(0)
+        model = build('depthformer_swint_a.py')
+        load_filled(model, 'cl')
+        model = model.to(dev).train()
+        if not amp:
+            set_exact(model)
+        if layout == 'nhwc':
+            to_channels_last(model)
+            assert model.backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last)
+        seen = []
+        h = model.neck.register_forward_hook(lambda m, i, o: seen.extend(kernels._is_cl(t) for t in o))
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            out = model.train_step(batch, None)
+        out['loss'].backward()
+        h.remove()
+        assert all(seen) == (layout == 'nhwc') and (layout == 'nchw' or any(seen)), (layout, seen)
+        res[layout] = (dict(out['log_vars']), torch.cat([p.grad.flatten().float() for p in model.parameters()]))
+    (la, ga), (lb, gb) = res['nhwc'], res['nchw']
+    for k in lb:
+        assert abs(la[k] - lb[k]) <= (2e-2 if amp else 2e-5) * abs(lb[k]) + 1e-6, (k, la[k], lb[k])
+    cos = torch.nn.functional.cosine_similarity(ga.double(), gb.double(), dim=0).item()
+    rel = ((ga - gb).double().norm() / gb.double().norm()).item()
+    print(f'\n[channels-last vs NCHW, amp={amp}] losses {la} | gradient l2rel {rel:.2e}, cosine {cos:.6f}')
+    assert rel <= (0.15 if amp else 2e-3) and cos >= (0.99 if amp else 0.999999), (rel, cos)

@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--height', type=int, default=352)
     ap.add_argument('--width', type=int, default=1120)
+    ap.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'])
+    ap.add_argument('--out-dir', default=None, help='also copy the updated tables here (e.g. gpurun_out/tuning on the GPU box)')
     a = ap.parse_args()
     work = tempfile.mkdtemp(prefix='gedepth_tune_')
     db = os.path.join(work, 'miopen')
@@ -39,7 +41,8 @@ def main():
     env = dict(os.environ, MIOPEN_USER_DB_PATH=db, GE_GEMM_TABLE=table, PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS='30',
                PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS='5')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', a.config, '--steps', '3', '--warmup', '3', '--no-cpu-baseline',
-           '--no-kernel-timing', '--cudnn-benchmark', '1', '--gemm-tuning', 'tune', '--height', str(a.height), '--width', str(a.width)]
+           '--no-kernel-timing', '--cudnn-benchmark', '1', '--gemm-tuning', 'tune', '--height', str(a.height), '--width', str(a.width), '--layout', a.layout,
+           '--no-fp32']
     if a.batch:
         cmd += ['--batch', str(a.batch)]
     subprocess.run(cmd, env=env, check=True)
@@ -47,6 +50,11 @@ def main():
     for f in os.listdir(db):
         if f.endswith('db.txt'):
             shutil.copy(os.path.join(db, f), os.path.join(TUNING, 'miopen', f))
+    if a.out_dir:
+        os.makedirs(os.path.join(a.out_dir, 'miopen'), exist_ok=True)
+        shutil.copy(os.path.join(TUNING, 'tunableop_gfx950.csv'), a.out_dir)
+        for f in os.listdir(os.path.join(TUNING, 'miopen')):
+            shutil.copy(os.path.join(TUNING, 'miopen', f), os.path.join(a.out_dir, 'miopen'))
     print(f'updated {TUNING}')
 
 
