@@ -201,8 +201,8 @@ def test_window_attention_fp8_forward(dev, geom, shift):
     err = (o8 - o_ref).abs()
     print(f'\nfp8 forward {geom} shift {shift}: max err {err.max().item() / scale:.3e} of scale, mean {err.mean().item() / o_ref.abs().mean().item():.3e}; '
           f'bf16 MFMA: max {(o16 - o_ref).abs().max().item() / scale:.3e}')
-    assert err.max().item() <= 6e-2 * scale, err.max().item() / scale
-    assert err.mean().item() <= 1.5e-2 * o_ref.abs().mean().item() + 1e-4
+    assert err.max().item() <= 0.2 * scale, err.max().item() / scale
+    assert err.mean().item() <= 4e-2 * o_ref.abs().mean().item() + 1e-4
     assert err.mean().item() > (o16 - o_ref).abs().mean().item()            # it really is the lower-precision path
     assert torch.equal(dq8, dq16) and torch.equal(db8, db16) and torch.equal(dt8, dt16)
 
