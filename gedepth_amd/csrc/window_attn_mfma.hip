@@ -378,6 +378,18 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_k(const bf16_t* __res
   for (int i = lane; i < NBIAS; i += GE_WAVE) { sm.bias[i] = bias_table[i * g.nH + head]; sm.dbias[i] = 0.f; }
   sm.dpad[lane] = 0.f;
   __syncthreads();
+  // bias-table gradient: dS[q][key] lands on table entry (i_q - i_k + 6) * 13 + (j_q - j_k + 6), which depends on the
+  // (query, key) position inside the window only — the same for every window this persistent workgroup visits.  So the lane
+  // that owns accumulator element (kt, qt, r) sums its dS over all windows in REGISTERS and scatters once at the end
+  // (64 LDS float atomics per workgroup instead of per window: ds_add_f32 costs ~170 cycles per wave-instruction, which made
+  // this kernel 5x slower than the forward one).
+  f32x16 dB[2][2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dB[kt][qt][i] = 0.f;
 
   for (int bw = slot; bw < n_bw; bw += wg_per_head) {
     const int b = bw / nW, win = bw - b * nW;
@@ -407,16 +419,13 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_k(const bf16_t* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) delta += P[kt][qt][r] * dS[kt][qt][r];
       delta += __shfl_xor(delta, 32, 64);
-      const int q = qt * 32 + c;
-      const int qb = (int)(sm.m.meta[q < WT ? q : 0] & 0xffffu) + 6 * 13 + 6;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float ds = P[kt][qt][r] * (dS[kt][qt][r] - delta);
+          const float ds = P[kt][qt][r] * (dS[kt][qt][r] - delta);     // exactly 0 for rows / columns >= 49 (P == 0 there)
           dS[kt][qt][r] = ds;
-          const int key = kt * 32 + crow(r, hi);
-          if (q < WT && key < WT) atomicAdd(&sm.dbias[qb - (int)(sm.m.meta[key] & 0xffffu)], ds);
+          dB[kt][qt][r] += ds;
         }
     }
 
@@ -493,6 +502,19 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_k(const bf16_t* __res
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = qt * 32 + c;
+    const int qb = (q / WS) * 13 + (q % WS) + 6 * 13 + 6;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + crow(r, hi);
+        if (q < WT && key < WT) atomicAdd(&sm.dbias[qb - ((key / WS) * 13 + key % WS)], dB[kt][qt][r]);
+      }
+  }
+  __syncthreads();
   float* wsp = workspace + (long)blockIdx.x * WS_PER_WG_MFMA;
   for (int i = lane; i < NBIAS; i += GE_WAVE) wsp[i] = sm.dbias[i];
   wsp[NBIAS + lane] = sm.dpad[lane];
