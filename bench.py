@@ -232,6 +232,7 @@ def main():
     step, per_gpu, optimizer = build_job(args, cfg, dev, rank, args.dtype)
 
     note(f'model built ({args.config}, {args.dtype}); warm-up + timed region')
+    kernels.FALLBACKS.clear()
     # ---- pass 1: the headline number; the per-kernel event profiler is OFF inside the timed region
     elapsed, out = timed_steps(step, args.warmup, args.steps, dev, world)
     loss = out['log_vars']['loss']
@@ -261,6 +262,8 @@ def main():
                        'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'layout': args.layout, 'window_attention': 'fp8-e4m3 mfma fwd' if args.attn == 'fp8' else 'bf16 mfma', 'last_loss': round(float(loss), 5),
                        'params': int(optimizer.arena.numel)},
         }
+        res['eager_fallbacks'] = dict(kernels.FALLBACKS)      # modules that took ATen where a HIP kernel exists: must be empty
+        assert not kernels.FALLBACKS, f'eager fall-backs inside the measured step: {kernels.FALLBACKS}'
         if prof:
             # the MSDA backward is several kernels behind one entry point: rank its kernels individually (timed by HIP events
             # inside the library), so that `roofline` is about ONE kernel whose name rocprofv3 reports too

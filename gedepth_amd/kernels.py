@@ -71,6 +71,16 @@ class _Profiler:
 
 PROFILER = _Profiler()
 
+# Ledger of the places where a module took ATen's generic kernels for a CUDA tensor although this library has a HIP kernel
+# for the op (shape / dtype / mode outside what the kernel covers).  Plumbing, not an error — but bench.py and the GPU tests
+# assert that the measured training step has none (DESIGN.md §1 "no eager fallback on the hot path").
+FALLBACKS = {}
+
+
+def note_fallback(site, why=''):
+    key = f'{site}: {why}' if why else site
+    FALLBACKS[key] = FALLBACKS.get(key, 0) + 1
+
 
 def _es(t):
     return t.element_size()

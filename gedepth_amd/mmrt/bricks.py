@@ -184,6 +184,9 @@ class LayerNorm(nn.LayerNorm):
             if torch.is_autocast_enabled():
                 out_dtype = torch.get_autocast_dtype('cuda') if self.autocast_out else torch.float32
             return kernels.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
+        if x.is_cuda:
+            from .. import kernels
+            kernels.note_fallback('LayerNorm', f'C={C} dtype={x.dtype}')
         return super().forward(x)
 
 
@@ -315,6 +318,9 @@ class ConvModule(nn.Module):
             if slope is not None:                       # training-mode BatchNorm2d (+ ReLU): the fused HIP kernels
                 from .. import kernels
                 return kernels.bn_act(x, self.norm, slope)
+        if x.is_cuda and (self.with_norm or self.with_activation) and self.training:
+            from .. import kernels
+            kernels.note_fallback('ConvModule', f'norm={type(self.norm).__name__ if self.with_norm else None} act={self.act_cfg}')
         if self.with_norm:
             x = self.norm(x)
         if self.with_activation:
@@ -358,6 +364,9 @@ class DropPath(nn.Module):
         divide / multiply / add over the token tensor.  Same random draw as ``drop_path`` (one uniform per sample)."""
         if (not identity.is_cuda or self.drop_prob == 0. or not self.training or identity.shape != branch.shape
                 or (identity.dtype, branch.dtype) not in _RESIDUAL_DTYPES):
+            if identity.is_cuda and self.training and self.drop_prob > 0.:
+                from .. import kernels
+                kernels.note_fallback('DropPath.residual', f'{identity.dtype}+{branch.dtype} {tuple(identity.shape)} vs {tuple(branch.shape)}')
             return identity + self(branch)
         from .. import kernels
         keep = 1 - self.drop_prob

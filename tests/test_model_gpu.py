@@ -225,6 +225,8 @@ def test_config2_bf16_full_shape_step_vs_fp32(dev):
     from gedepth_amd.depth.datasets.synthetic import synthetic_batch
     from gedepth_amd.mmrt.config import Config
     from gedepth_amd.mmrt.optim import build_optimizer
+    from gedepth_amd import kernels as _k
+    _k.FALLBACKS.clear()
     torch.manual_seed(0)
     model = build('depthformer_swint_v.py')
     model.init_weights()
@@ -248,6 +250,8 @@ def test_config2_bf16_full_shape_step_vs_fp32(dev):
     print(f'\n[config #2 8x352x1120] loss fp32 {l32:.6f} bf16 {l16:.6f} rel {abs(l16 - l32) / abs(l32):.2e}; '
           f'grad cosine {cos:.5f}, |g_bf16|/|g_fp32| {nrm:.4f}')
     _log_parity('config2_bf16_vs_fp32', dict(loss_fp32=l32, loss_bf16=l16, grad_cosine=cos, grad_norm_ratio=nrm))
+    from gedepth_amd import kernels
+    assert not kernels.FALLBACKS, f'modules fell back to ATen on the hot path: {kernels.FALLBACKS}'
     assert abs(l16 - l32) <= 1e-2 * abs(l32), (l16, l32)        # bf16 has 8 mantissa bits: 4e-3 per rounding
     assert torch.isfinite(g16).all() and cos >= 0.98 and 0.9 <= nrm <= 1.1, (cos, nrm)
     optimizer.step()
