@@ -19,7 +19,7 @@ def set_random_seed(seed, deterministic=False):
 
 
 def train_depther(model, dataset, cfg, distributed=False, validate=False, timestamp=None, meta=None, logger=print,
-                  evaluate_fn=None, data_loaders=None, device=None):
+                  evaluate_fn=None, data_loaders=None, device=None, batch_transform=None, channels_last=False):
     """``dataset``: a map-style dataset (or list of them) yielding dict samples; alternatively pass ready
     ``data_loaders``.  ``evaluate_fn(runner) -> dict`` plays DistEvalHook's role when ``validate``."""
     device = device or torch.device('cuda', torch.cuda.current_device())
@@ -29,6 +29,9 @@ def train_depther(model, dataset, cfg, distributed=False, validate=False, timest
         data_loaders = [build_dataloader(ds, cfg.data.samples_per_gpu, cfg.data.workers_per_gpu, dist=distributed,
                                          seed=cfg.get('seed'), drop_last=True) for ds in datasets]
     model = model.to(device)
+    if channels_last:                                           # before the optimizer: the parameter arena keeps the NHWC weight order
+        from ..models.utils import to_channels_last
+        to_channels_last(model)
     optimizer = build_optimizer(model, cfg.optimizer, cfg.get('optimizer_config', {}).get('grad_clip'))
     wrapped = FlatDDP(model, optimizer.arena) if distributed else model
     if cfg.get('runner') is None:
@@ -37,6 +40,7 @@ def train_depther(model, dataset, cfg, distributed=False, validate=False, timest
     amp = torch.bfloat16 if cfg.get('amp', 'bf16') == 'bf16' else None
     runner = IterBasedRunner(wrapped, optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta,
                              max_iters=cfg.runner['max_iters'], amp_dtype=amp)
+    runner.batch_transform = batch_transform
     if timestamp:
         runner.timestamp = timestamp
     runner.register_training_hooks(cfg.lr_config, dict(grad_clip=cfg.get('optimizer_config', {}).get('grad_clip')),

@@ -164,6 +164,7 @@ class IterBasedRunner:
         self.max_iters = max_iters
         self.iter = 0
         self.epoch = 0
+        self.batch_transform = None
         self.hooks = []
         self.outputs = None
         self.current_lr = optimizer.defaults['lr']
@@ -228,7 +229,9 @@ class IterBasedRunner:
                 self._set_epoch(loader, self.epoch)
                 it = iter(loader)
                 batch = next(it)
-            batch = self._to_device(batch, device)
+            # batch_transform: a device-side data pipeline (depth/datasets/gpu_pipeline.py) turns the loader's raw samples into
+            # the batch dict; otherwise the collated host batch is staged with non-blocking copies
+            batch = self.batch_transform(batch) if self.batch_transform is not None else self._to_device(batch, device)
             self.call_hook('before_train_iter')
             self.optimizer.zero_grad()
             if self.amp_dtype is not None:

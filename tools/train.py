@@ -40,6 +40,11 @@ def parse_args():
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic KITTI-shaped samples')
     p.add_argument('--fp32', action='store_true', help='disable bf16 autocast')
+    p.add_argument('--gpu-pipeline', action='store_true',
+                   help='KITTI: loader workers only decode files; ground depth from the calibration and every transform of the train '
+                        'pipeline run on the GPU (gedepth_amd/depth/datasets/gpu_pipeline.py, SURVEY.md §8 f3)')
+    p.add_argument('--pe-source', default='calib', choices=['calib', 'npy'], help='--gpu-pipeline: ground depth from the calibration files or from pe_165.npy')
+    p.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'], help='nhwc: channels-last conv stack (depth/models/utils/layout.py)')
     p.add_argument('--gemm-tuning', default='load', choices=['off', 'load', 'tune'],
                    help='hipBLASLt/rocBLAS solution table for the Linear layers (gedepth_amd/mmrt/tuning.py)')
     return p.parse_args()
@@ -80,14 +85,26 @@ def main():
         cfg.model.pretrained = None
     model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     model.init_weights()
-    evaluate_fn = None
+    evaluate_fn = data_loaders = batch_transform = None
     if args.synthetic > 0:
         h, w = cfg.get('crop_size', (352, 1120))
         dataset = SyntheticKITTI(args.synthetic, h, w, adaptive='dynamic_pe_neck' in cfg.model, seed=1234)
     else:                                                     # the KITTI tree of cfg.data (depth/datasets/kitti.py)
         from gedepth_amd.depth.apis.test import multi_gpu_test
         from gedepth_amd.depth.datasets import build_dataloader, build_dataset
-        dataset = build_dataset(cfg.data.train)
+        if args.gpu_pipeline:
+            from gedepth_amd.depth.datasets.gpu_pipeline import KITTIGPUPipeline, KITTIRawDataset, raw_collate
+            t = cfg.data.train
+            dataset = KITTIRawDataset(img_dir=t.img_dir, ann_dir=t.ann_dir, split=t.split, data_root=t.get('data_root'),
+                                      depth_scale=t.get('depth_scale', 256))
+            sampler = torch.utils.data.DistributedSampler(dataset, world, rank, shuffle=True, seed=args.seed or 0) if distributed else None
+            data_loaders = [torch.utils.data.DataLoader(dataset, batch_size=cfg.data.samples_per_gpu, sampler=sampler, shuffle=sampler is None,
+                                                        num_workers=cfg.data.workers_per_gpu, collate_fn=raw_collate, drop_last=True,
+                                                        persistent_workers=cfg.data.workers_per_gpu > 0)]
+            batch_transform = KITTIGPUPipeline(data_root=t.get('data_root'), img_dir=t.img_dir, pe_source=args.pe_source,
+                                               depth_scale=t.get('depth_scale', 256)).batch
+        else:
+            dataset = build_dataset(cfg.data.train)
         if not args.no_validate:
             val_set = build_dataset(cfg.data.val, dict(test_mode=True))
             val_loader = build_dataloader(val_set, 1, cfg.data.workers_per_gpu, dist=distributed, shuffle=False)
@@ -99,7 +116,8 @@ def main():
     meta = dict(gedepth_amd_version=__version__, config=cfg.pretty_text, seed=args.seed)
     log = (lambda m: print(m, flush=True)) if rank == 0 else (lambda m: None)
     train_depther(model, dataset, cfg, distributed=distributed, validate=not args.no_validate, timestamp=timestamp,
-                  meta=meta, logger=log, evaluate_fn=evaluate_fn)
+                  meta=meta, logger=log, evaluate_fn=evaluate_fn, data_loaders=data_loaders, batch_transform=batch_transform,
+                  channels_last=args.layout == 'nhwc')
 
 
 if __name__ == '__main__':
