@@ -23,27 +23,35 @@
 template <int K, int VN>
 __device__ __forceinline__ void nh_col_commit(float (&acc)[K][VN], double* __restrict__ ws, int C, int lpr, int rpi, int c0) {
   __shared__ float sm[K][NH_MAXLANES][VN];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, rs = t / lpr;
 #pragma unroll
   for (int k = 0; k < K; ++k)
 #pragma unroll
     for (int v = 0; v < VN; ++v) sm[k][t][v] = acc[k][v];
   __syncthreads();
+  int span = 1;
+  while (span < rpi) span <<= 1;
+  for (int stride = span >> 1; stride > 0; stride >>= 1) {          // tree over the row slots: all of them work
+    if (rs < stride && rs + stride < rpi) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int v = 0; v < VN; ++v) sm[k][t][v] += sm[k][t + stride * lpr][v];
+    }
+    __syncthreads();
+  }
   if (t < lpr) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int v = 0; v < VN; ++v) {
-        float s = 0.f;
-        for (int j = 0; j < rpi; ++j) s += sm[k][j * lpr + t][v];
-        atomicAdd(&ws[(long)k * C + c0 + v], (double)s);
-      }
+      for (int v = 0; v < VN; ++v) atomicAdd(&ws[(long)k * C + c0 + v], (double)sm[k][t][v]);
   }
 }
+// few, long-running workgroups: every one of them ends in C same-address fp64 atomics, which serialise in L2
 static inline unsigned nh_grid_rows(long R, int rpi) {
-  long b = (R + (long)rpi * 8 - 1) / ((long)rpi * 8);
+  long b = (R + (long)rpi * 16 - 1) / ((long)rpi * 16);
   if (b < 1) b = 1;
-  if (b > 4096) b = 4096;
+  if (b > 512) b = 512;
   return (unsigned)b;
 }
 
@@ -67,15 +75,20 @@ __global__ void __launch_bounds__(256) bn_stats_nhwc_k(const T* __restrict__ x, 
 }
 template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_nhwc_k(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y, int C,
-                                                       long nvec, int lpr, float slope) {
+                                                       long R, int lpr, int rpi, float slope) {
   constexpr int VN = V8<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c0 = (int)(i % lpr) * VN;
-    float v[VN];
-    V8<T>::ld(x + i * VN, v);
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  if (rs >= rpi) return;
+  const int c0 = lane * VN;
+  float a[VN], b[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) { const float tv = v[k] * coef[c0 + k] + coef[C + c0 + k]; v[k] = tv > 0.f ? tv : tv * slope; }
-    V8<T>::st(y + i * VN, v);
+  for (int k = 0; k < VN; ++k) { a[k] = coef[c0 + k]; b[k] = coef[C + c0 + k]; }
+  for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
+    float v[VN];
+    V8<T>::ld(x + r * C + c0, v);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { const float tv = v[k] * a[k] + b[k]; v[k] = tv > 0.f ? tv : tv * slope; }
+    V8<T>::st(y + r * C + c0, v);
   }
 }
 template <typename T>
@@ -106,22 +119,28 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_nhwc_k(const T* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_nhwc_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                           const float* __restrict__ coef, T* __restrict__ dx, int C, long nvec, int lpr,
+                                                           const float* __restrict__ coef, T* __restrict__ dx, int C, long R, int lpr, int rpi,
                                                            float slope) {
   constexpr int VN = V8<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c0 = (int)(i % lpr) * VN;
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  if (rs >= rpi) return;
+  const int c0 = lane * VN;
+  float a[VN], m1[VN], m2[VN], mu[VN], rsd[VN];
+#pragma unroll
+  for (int k = 0; k < VN; ++k) {
+    a[k] = coef[c0 + k]; m1[k] = coef[C + c0 + k]; m2[k] = coef[2 * C + c0 + k]; mu[k] = save_mean[c0 + k]; rsd[k] = save_rstd[c0 + k];
+  }
+  for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
     float g[VN], yv[VN], xv[VN];
-    V8<T>::ld(dy + i * VN, g);
-    V8<T>::ld(y + i * VN, yv);
-    V8<T>::ld(x + i * VN, xv);
+    V8<T>::ld(dy + r * C + c0, g);
+    V8<T>::ld(y + r * C + c0, yv);
+    V8<T>::ld(x + r * C + c0, xv);
 #pragma unroll
     for (int k = 0; k < VN; ++k) {
-      const int c = c0 + k;
       const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
-      g[k] = coef[c] * (gg - coef[C + c] - ((xv[k] - save_mean[c]) * save_rstd[c]) * coef[2 * C + c]);
+      g[k] = a[k] * (gg - m1[k] - ((xv[k] - mu[k]) * rsd[k]) * m2[k]);
     }
-    V8<T>::st(dx + i * VN, g);
+    V8<T>::st(dx + r * C + c0, g);
   }
 }
 
@@ -169,6 +188,12 @@ static inline bool nh_aligned(const void* a, const void* b = nullptr, const void
   return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
 }
 static inline unsigned nh_grid_vec(long nvec) { return ge_blocks(nvec, 256 * 4, 65536); }
+static inline unsigned nh_grid_apply(long R, int rpi) {           // ~4 rows per thread, enough workgroups to fill 256 CUs several times
+  long b = (R + (long)rpi * 4 - 1) / ((long)rpi * 4);
+  if (b < 1) b = 1;
+  if (b > 16384) b = 16384;
+  return (unsigned)b;
+}
 
 // workspace: same layout / size as ge_bn_workspace(C): double[2C] sums + float[3C] coefficients
 template <typename T>
@@ -185,8 +210,7 @@ static int bn_nhwc_fwd_launch(const void* x, const float* gamma, const float* be
   GE_LAUNCH_CHECK();
   bn_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, beta, save_mean, save_rstd, running_mean, running_var, coef, C, (double)R, eps, momentum);
   GE_LAUNCH_CHECK();
-  const long nvec = R * lpr;
-  bn_apply_nhwc_k<T><<<nh_grid_vec(nvec), 256, 0, s>>>((const T*)x, coef, (T*)y, C, nvec, lpr, slope);
+  bn_apply_nhwc_k<T><<<nh_grid_apply(R, rpi), 256, 0, s>>>((const T*)x, coef, (T*)y, C, R, lpr, rpi, slope);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
@@ -204,8 +228,7 @@ static int bn_nhwc_bwd_launch(const void* dy, const void* y, const void* x, cons
   GE_LAUNCH_CHECK();
   bn_bwd_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, save_rstd, dgamma, dbeta, coef, C, (double)R);
   GE_LAUNCH_CHECK();
-  const long nvec = R * lpr;
-  bn_bwd_apply_nhwc_k<T><<<nh_grid_vec(nvec), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, coef, (T*)dx, C, nvec, lpr, slope);
+  bn_bwd_apply_nhwc_k<T><<<nh_grid_apply(R, rpi), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, coef, (T*)dx, C, R, lpr, rpi, slope);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
@@ -228,15 +251,21 @@ extern "C" int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, 
 
 // ============================================================================================ bias + LeakyReLU
 template <typename T>
-__global__ void __launch_bounds__(256) bias_act_nhwc_fwd_k(T* __restrict__ x, const float* __restrict__ bias, long nvec, int lpr, float slope) {
+__global__ void __launch_bounds__(256) bias_act_nhwc_fwd_k(T* __restrict__ x, const float* __restrict__ bias, int C, long R, int lpr, int rpi,
+                                                           float slope) {
   constexpr int VN = V8<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c0 = (int)(i % lpr) * VN;
-    float v[VN];
-    V8<T>::ld(x + i * VN, v);
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  if (rs >= rpi) return;
+  const int c0 = lane * VN;
+  float b[VN];
 #pragma unroll
-    for (int k = 0; k < VN; ++k) { const float tv = v[k] + bias[c0 + k]; v[k] = tv > 0.f ? tv : tv * slope; }
-    V8<T>::st(x + i * VN, v);
+  for (int k = 0; k < VN; ++k) b[k] = bias[c0 + k];
+  for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
+    float v[VN];
+    V8<T>::ld(x + r * C + c0, v);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) { const float tv = v[k] + b[k]; v[k] = tv > 0.f ? tv : tv * slope; }
+    V8<T>::st(x + r * C + c0, v);
   }
 }
 // dx = dy * act'(y); d_bias (fp64 workspace, C doubles, zeroed by the launcher) = column sums of dx
@@ -270,10 +299,10 @@ extern "C" int ge_bias_act_nhwc_fwd(void* x, const float* bias, long rows, int C
   hipStream_t s = ge_stream(stream);
   if (dtype == GE_F32) {
     if (!nh_geom<float>(C, lpr, rpi) || !nh_aligned(x)) return GE_ERR_UNSUPPORTED;
-    bias_act_nhwc_fwd_k<float><<<nh_grid_vec(rows * lpr), 256, 0, s>>>((float*)x, bias, rows * lpr, lpr, slope);
+    bias_act_nhwc_fwd_k<float><<<nh_grid_apply(rows, rpi), 256, 0, s>>>((float*)x, bias, C, rows, lpr, rpi, slope);
   } else if (dtype == GE_BF16) {
     if (!nh_geom<bf16_t>(C, lpr, rpi) || !nh_aligned(x)) return GE_ERR_UNSUPPORTED;
-    bias_act_nhwc_fwd_k<bf16_t><<<nh_grid_vec(rows * lpr), 256, 0, s>>>((bf16_t*)x, bias, rows * lpr, lpr, slope);
+    bias_act_nhwc_fwd_k<bf16_t><<<nh_grid_apply(rows, rpi), 256, 0, s>>>((bf16_t*)x, bias, C, rows, lpr, rpi, slope);
   } else {
     return GE_ERR_UNSUPPORTED;
   }

@@ -279,9 +279,9 @@ def _is_cl(x):
 
 
 def _cl_ok(x):
-    """NHWC kernels apply: channels-last storage, C a multiple of the 16-byte vector and <= 2048."""
+    """NHWC kernels apply: channels-last storage, C a multiple of the 16-byte vector and at most 256 vectors wide."""
     vn = 8 if x.dtype == torch.bfloat16 else 4
-    return x.is_cuda and _is_cl(x) and x.shape[1] % vn == 0 and x.shape[1] <= 2048 and x.dtype in (_f32, torch.bfloat16)
+    return (x.is_cuda and _is_cl(x) and x.shape[1] % vn == 0 and x.shape[1] // vn <= 256 and x.dtype in (_f32, torch.bfloat16))
 
 
 def _cl(x):

@@ -271,7 +271,7 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
  * Channels-last (NHWC) variants of the map kernels (csrc/nhwc.hip).  A channels-last map (B, C, H, W) with strides
  * (HWC, 1, WC, C) is the row matrix (rows = B*H*W, C): MIOpen's bf16 implicit-GEMM convolutions run on it without their
  * NCHW <-> NHWC batched_transpose kernels, and tokens <-> maps become views.  C must be a multiple of the 16-byte vector
- * (8 bf16 / 4 f32) and <= 2048, pointers 16-byte aligned; otherwise GE_ERR_UNSUPPORTED (the caller keeps NCHW).
+ * (8 bf16 / 4 f32) and at most 256 such vectors wide, pointers 16-byte aligned; otherwise GE_ERR_UNSUPPORTED (the caller keeps NCHW).
  * ge_bn_act_nhwc_*: as ge_bn_act_* (same workspace size, ge_bn_workspace(C)); statistics are column sums.
  * ge_bias_act_nhwc_*: as ge_bias_act_*; the backward needs a workspace of C doubles, d_bias is fully written.
  * ge_bilinear_nhwc_*: as ge_bilinear_* on (N, H, W, C).
