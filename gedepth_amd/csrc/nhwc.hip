@@ -411,10 +411,87 @@ __global__ void __launch_bounds__(256) bilinear_nhwc_bwd_k(const T* __restrict__
     V8<T>::st(gin + ((n * Hi + Y) * (long)Wi + X) * C + c0, acc);
   }
 }
+// Large up-sampling factors (the PE necks bring 11x35 maps to 176x560): a gather over (2f)^2 candidate outputs per input
+// element leaves too few, too long threads.  Bilinear interpolation is separable, so is its transpose:
+//   horizontal: tmp[n, oy, X, c] = sum_ox wx(ox -> X) g[n, oy, ox, c]     (N * Ho * Wi * C/VN threads, ~2f taps each, fp32 tmp)
+//   vertical  : gin[n, Y, X, c]  = sum_oy wy(oy -> Y) tmp[n, oy, X, c]
 template <typename T>
-static int bilinear_nhwc_launch(bool fwd, const void* src, void* dst, int N, int C, int Hi, int Wi, int Ho, int Wo, int align, hipStream_t s) {
+__global__ void __launch_bounds__(256) bilinear_nhwc_bwd_h_k(const T* __restrict__ gout, float* __restrict__ tmp, int N, int Wi, int Ho, int Wo,
+                                                             int C, int lpr, int align) {
+  constexpr int VN = V8<T>::N;
+  const float sx = ge_scale(Wi, Wo, align);
+  const long total = (long)N * Ho * Wi * lpr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c0 = (int)(idx % lpr) * VN;
+    long t = idx / lpr;
+    const int X = (int)(t % Wi);
+    const long row = t / Wi;                                  // n * Ho + oy
+    int xlo, xhi;
+    nh_cand_range(X, Wi, Wo, sx, align, xlo, xhi);
+    const T* g = gout + row * (long)Wo * C + c0;
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    for (int ox = xlo; ox <= xhi; ++ox) {
+      const Lerp lx = ge_lerp(ox, Wi, sx, align);
+      const float wx = (lx.i0 == X ? lx.w0 : 0.f) + (lx.i1 == X ? lx.w1 : 0.f);
+      if (wx == 0.f) continue;
+      float v[VN];
+      V8<T>::ld(g + (long)ox * C, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[k] += wx * v[k];
+    }
+    float* o = tmp + (row * Wi + X) * (long)C + c0;
+#pragma unroll
+    for (int k = 0; k < VN; k += 4) *(float4*)(o + k) = make_float4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_nhwc_bwd_v_k(const float* __restrict__ tmp, T* __restrict__ gin, int N, int Hi, int Wi, int Ho,
+                                                             int C, int lpr, int align) {
+  constexpr int VN = V8<T>::N;
+  const float sy = ge_scale(Hi, Ho, align);
+  const long total = (long)N * Hi * Wi * lpr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c0 = (int)(idx % lpr) * VN;
+    long t = idx / lpr;
+    const int X = (int)(t % Wi); t /= Wi;
+    const int Y = (int)(t % Hi);
+    const long n = t / Hi;
+    int ylo, yhi;
+    nh_cand_range(Y, Hi, Ho, sy, align, ylo, yhi);
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const Lerp ly = ge_lerp(oy, Hi, sy, align);
+      const float wy = (ly.i0 == Y ? ly.w0 : 0.f) + (ly.i1 == Y ? ly.w1 : 0.f);
+      if (wy == 0.f) continue;
+      const float* p = tmp + ((n * Ho + oy) * (long)Wi + X) * C + c0;
+#pragma unroll
+      for (int k = 0; k < VN; k += 4) {
+        const float4 q = *(const float4*)(p + k);
+        acc[k] += wy * q.x; acc[k + 1] += wy * q.y; acc[k + 2] += wy * q.z; acc[k + 3] += wy * q.w;
+      }
+    }
+    V8<T>::st(gin + ((n * Hi + Y) * (long)Wi + X) * C + c0, acc);
+  }
+}
+
+template <typename T>
+static int bilinear_nhwc_launch(bool fwd, const void* src, void* dst, int N, int C, int Hi, int Wi, int Ho, int Wo, int align, hipStream_t s,
+                                void* workspace = nullptr, size_t workspace_bytes = 0) {
   int lpr, rpi;
   if (!nh_geom<T>(C, lpr, rpi) || !nh_aligned(src, dst)) return GE_ERR_UNSUPPORTED;
+  if (!fwd && workspace && (Ho > 3 * Hi || Wo > 3 * Wi) && workspace_bytes >= (size_t)N * Ho * Wi * C * sizeof(float) && nh_aligned(workspace)) {
+    const long th = (long)N * Ho * Wi * lpr, tv = (long)N * Hi * Wi * lpr;
+    if (th == 0 || tv == 0) return GE_OK;
+    bilinear_nhwc_bwd_h_k<T><<<ge_blocks(th, 256, 1 << 18), 256, 0, s>>>((const T*)src, (float*)workspace, N, Wi, Ho, Wo, C, lpr, align);
+    GE_LAUNCH_CHECK();
+    bilinear_nhwc_bwd_v_k<T><<<ge_blocks(tv, 256, 1 << 18), 256, 0, s>>>((const float*)workspace, (T*)dst, N, Hi, Wi, Ho, C, lpr, align);
+    GE_LAUNCH_CHECK();
+    return GE_OK;
+  }
   if (fwd) {
     const long total = (long)N * Ho * Wo * lpr;
     if (total == 0) return GE_OK;
@@ -435,12 +512,13 @@ extern "C" int ge_bilinear_nhwc_fwd(const void* in, void* out, int N, int C, int
   if (dtype == GE_BF16) return bilinear_nhwc_launch<bf16_t>(true, in, out, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
   return GE_ERR_UNSUPPORTED;
 }
-// d_out (N, Ho, Wo, C) -> d_in (N, Hi, Wi, C), fully written
-extern "C" int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners, int dtype,
-                                    void* stream) {
+// d_out (N, Ho, Wo, C) -> d_in (N, Hi, Wi, C), fully written.  workspace (optional, N * Ho * Wi * C floats): enables the separable
+// two-pass form for up-sampling factors > 3.
+extern "C" int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, void* workspace, size_t workspace_bytes, int N, int C, int Hi, int Wi, int Ho,
+                                    int Wo, int align_corners, int dtype, void* stream) {
   if (!d_out || !d_in || N < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return GE_ERR_BAD_ARG;
-  if (dtype == GE_F32) return bilinear_nhwc_launch<float>(false, d_out, d_in, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
-  if (dtype == GE_BF16) return bilinear_nhwc_launch<bf16_t>(false, d_out, d_in, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream));
+  if (dtype == GE_F32) return bilinear_nhwc_launch<float>(false, d_out, d_in, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream), workspace, workspace_bytes);
+  if (dtype == GE_BF16) return bilinear_nhwc_launch<bf16_t>(false, d_out, d_in, N, C, Hi, Wi, Ho, Wo, align_corners, ge_stream(stream), workspace, workspace_bytes);
   return GE_ERR_UNSUPPORTED;
 }
 

@@ -59,7 +59,7 @@ SIGNATURES = {
     'ge_bias_act_nhwc_fwd': (_i, [_vp, _vp, _l, _i, _f, _i, _vp]),
     'ge_bias_act_nhwc_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     'ge_bilinear_nhwc_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    'ge_bilinear_nhwc_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_bilinear_nhwc_bwd': (_i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_concat_rows_fwd': (_i, [_vp, _l, _l, _vp, _vp, _vp, _l, _i, _i, _i, _f, _u64, _i, _vp]),
     'ge_slice_rows_drop': (_i, [_vp, _vp, _l, _i, _i, _i, _f, _u64, _i, _vp]),
     'ge_add_rows': (_i, [_vp, _vp, _vp, _i, _l, _i, _i, _vp]),

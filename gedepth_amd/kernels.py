@@ -500,8 +500,10 @@ class _Bilinear(torch.autograd.Function):
         if ctx.cl:
             d_out = _cl(d_out)
             d_in = torch.empty((N, C, Hi, Wi), device=d_out.device, dtype=d_out.dtype, memory_format=_CL)
+            ws = torch.empty(N * Ho * Wi * C, device=d_out.device, dtype=_f32) if (Ho > 3 * Hi or Wo > 3 * Wi) else None
             PROFILER.run(f'bilinear_nhwc_bwd[{N}x{C} {Hi}x{Wi}<-{Ho}x{Wo} {_tag(d_out)}]', (d_out.numel() + d_in.numel()) * _es(d_out),
-                         lambda: hip.check(hip.lib().ge_bilinear_nhwc_bwd(_raw_ptr(d_out, 'd_out'), _raw_ptr(d_in, 'd_in'), N, C, Hi, Wi, Ho, Wo, ac,
+                         lambda: hip.check(hip.lib().ge_bilinear_nhwc_bwd(_raw_ptr(d_out, 'd_out'), _raw_ptr(d_in, 'd_in'), hip.ptr(ws),
+                                                                          0 if ws is None else ws.numel() * 4, N, C, Hi, Wi, Ho, Wo, ac,
                                                                           hip.dtype_code(d_out), hip.stream()), 'ge_bilinear_nhwc_bwd'))
             return d_in, None, None, None
         d_out = _c(d_out)

@@ -274,7 +274,8 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
  * (8 bf16 / 4 f32) and at most 256 such vectors wide, pointers 16-byte aligned; otherwise GE_ERR_UNSUPPORTED (the caller keeps NCHW).
  * ge_bn_act_nhwc_*: as ge_bn_act_* (same workspace size, ge_bn_workspace(C)); statistics are column sums.
  * ge_bias_act_nhwc_*: as ge_bias_act_*; the backward needs a workspace of C doubles, d_bias is fully written.
- * ge_bilinear_nhwc_*: as ge_bilinear_* on (N, H, W, C).
+ * ge_bilinear_nhwc_*: as ge_bilinear_* on (N, H, W, C); the backward takes an optional workspace of N*Ho*Wi*C floats that
+ *   enables the separable two-pass form for up-sampling factors > 3 (PE necks: 11x35 -> 176x560).
  * ge_concat_rows_fwd: out (rows, Ca+Cb) = [a * dropout + res | b] (a first) or [b | a * dropout + res]; `a` is B batches
  *   of rows_per_batch packed rows with a free batch stride (a token range of a longer sequence), res / b / out dense:
  *   torch.cat([to_map(dropout(tokens)) + identity, fmap], 1) of necks/hahi.py:326-346 on channels-last maps.
@@ -292,8 +293,8 @@ int ge_bias_act_nhwc_bwd(const void* dy, const void* y, void* dx, float* dbias, 
                          float slope, int dtype, void* stream);
 int ge_bilinear_nhwc_fwd(const void* in, void* out, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
                          int dtype, void* stream);
-int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, int N, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
-                         int dtype, void* stream);
+int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, void* workspace, size_t workspace_bytes, int N, int C, int Hi, int Wi,
+                         int Ho, int Wo, int align_corners, int dtype, void* stream);
 int ge_concat_rows_fwd(const void* a, long rows_per_batch, long a_batch_stride, const void* res, const void* b, void* out,
                        long rows, int Ca, int Cb, int a_first, float p_drop, unsigned long long seed, int dtype,
                        void* stream);

@@ -1118,7 +1118,8 @@ def test_nhwc_bn_act_bias_act_bilinear_match_nchw(dev, dtype, geom):
         (close_scaled(a, b, rel=2e-2 if dtype == 'bf16' else 1e-4, what=f'bias_act nhwc {n}') if n == 'dbias'
          else close(a, b, what=f'bias_act nhwc {n}', **tol))
 
-    for size, align in (((2 * H, 2 * W), True), ((2 * H, 2 * W), False), ((max(1, H // 2), max(1, W // 2)), True), ((3 * H + 1, 2 * W - 1), False)):
+    for size, align in (((2 * H, 2 * W), True), ((2 * H, 2 * W), False), ((max(1, H // 2), max(1, W // 2)), True), ((3 * H + 1, 2 * W - 1), False),
+                        ((16 * H, 16 * W), True), ((5 * H + 2, 4 * W), False)):          # factors > 3: the separable two-pass backward
         def bil_run(cl):
             xi = x.to(dev)
             xi = (_cl(xi) if cl else xi).requires_grad_(True)
