@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-fp32 --no-kernel-timing"
+ARGS="--no-cpu-baseline --no-fp32 --no-kernel-timing ${BENCH_EXTRA:-}"      # e.g. BENCH_EXTRA="--layout nchw"
 # warm MIOpen / TunableOp caches in this session (a cold MIOpen under rocprofv3 falls back to naive_conv kernels)
 python $REPO/bench.py --steps 3 --warmup 3 $ARGS > $OUT/warm.json 2> $OUT/warm.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $REPO/bench.py --steps 20 --warmup 5 $ARGS > $OUT/stats_bench.json 2> $OUT/stats.err
