@@ -553,12 +553,13 @@ extern "C" int ge_sumsq(const float* x, long n, double* out, void* stream) {
   return GE_OK;
 }
 
-// hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm}
+// hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm, 1 - beta1, 1 - beta2}; the last two are rounded
+// from the host's double like torch.optim's `value=1 - beta2` (1.f - 0.999f is 1.3e-5 off 0.001f)
 __global__ void __launch_bounds__(256) adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, const uint8_t* __restrict__ wdm,
                                                const float* __restrict__ hyper, const double* __restrict__ gnorm_sq, long n) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6],
-              max_norm = hyper[7];
+              max_norm = hyper[7], omb1 = hyper[8], omb2 = hyper[9];
   float clip = 1.f;
   if (max_norm > 0.f && gnorm_sq) {
     float total = (float)sqrt(gnorm_sq[0]);
@@ -568,8 +569,8 @@ __global__ void __launch_bounds__(256) adamw_k(float* __restrict__ p, const floa
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gi = g[i] * clip, pi = p[i], mi = m[i], vi = v[i];
     if (wdm[i]) pi *= 1.f - lr * wd;
-    mi = b1 * mi + (1.f - b1) * gi;
-    vi = b2 * vi + (1.f - b2) * gi * gi;
+    mi = b1 * mi + omb1 * gi;
+    vi = b2 * vi + omb2 * gi * gi;
     float denom = sqrtf(vi) * rs2 + eps;
     pi -= step * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;

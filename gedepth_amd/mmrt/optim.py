@@ -92,9 +92,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 self.wd_mask[off:off + n] = 1
         self.max_grad_norm = float(max_grad_norm)
         self.step_count = 0
-        self.hyper = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.hyper = torch.zeros(10, device=dev, dtype=torch.float32)
         # ring of pinned staging buffers: the H2D copy of the step scalars never blocks the host
-        self._ring = [(torch.zeros(8, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+        self._ring = [(torch.zeros(10, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
 
     def sync_grads_from_params(self):
@@ -119,7 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
         host, ev = self._ring[t % len(self._ring)]
         ev.synchronize()                       # slot was used 8 steps ago: already complete in practice
         host.copy_(torch.tensor([g0['lr'], b1, b2, g0['eps'], self.base_wd, 1 - b1 ** t, 1 - b2 ** t,
-                                 self.max_grad_norm], dtype=torch.float32))
+                                 self.max_grad_norm, 1 - b1, 1 - b2], dtype=torch.float32))      # 1 - beta in double, like torch
         self.hyper.copy_(host, non_blocking=True)
         ev.record()
         lib, a = hip.lib(), self.arena

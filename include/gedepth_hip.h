@@ -353,7 +353,8 @@ int ge_silog_bwd(const float* pred, const float* gt, float eps, const float* coe
  *       p *= 1 - lr*wd[seg(i)];  m,v updates;  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
  *     decay is per element via `wd_mask` (u8: 1 = apply weight decay) to honour paramwise decay_mult=0.
  *     lr / step-dependent scalars are read from a small device array `hyper` =
- *     {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm} so that the launch can
+ *     {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm, 1-beta1, 1-beta2} (10 floats; the last two
+ *     rounded from double on the host, as torch.optim does) so that the launch can
  *     be captured in a hipGraph and replayed while the host updates `hyper`.
  */
 int ge_sumsq(const float* x, long n, double* out, void* stream);
