@@ -555,9 +555,13 @@ extern "C" int ge_sumsq(const float* x, long n, double* out, void* stream) {
 
 // hyper = {lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, max_norm, 1 - beta1, 1 - beta2}; the last two are rounded
 // from the host's double like torch.optim's `value=1 - beta2` (1.f - 0.999f is 1.3e-5 off 0.001f)
+// SHADOW: also write the updated parameter rounded to bf16 into a second arena — the low-precision copy the autocast forward reads,
+// so that no per-tensor cast kernel runs in the next step (mmrt/optim.py)
+template <bool SHADOW>
 __global__ void __launch_bounds__(256) adamw_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, const uint8_t* __restrict__ wdm,
-                                               const float* __restrict__ hyper, const double* __restrict__ gnorm_sq, long n) {
+                                               const float* __restrict__ hyper, const double* __restrict__ gnorm_sq, long n,
+                                               bf16_t* __restrict__ shadow) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6],
               max_norm = hyper[7], omb1 = hyper[8], omb2 = hyper[9];
   float clip = 1.f;
@@ -574,13 +578,24 @@ __global__ void __launch_bounds__(256) adamw_k(float* __restrict__ p, const floa
     float denom = sqrtf(vi) * rs2 + eps;
     pi -= step * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
+    if (SHADOW) shadow[i] = f2bf(pi);
   }
 }
 extern "C" int ge_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* wd_mask,
                              const float* hyper, const double* gnorm_sq, long n, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !wd_mask || !hyper || n < 0) return GE_ERR_BAD_ARG;
   if (n == 0) return GE_OK;
-  adamw_k<<<ge_blocks(n, 256 * 4, 8192), 256, 0, ge_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, wd_mask, hyper, gnorm_sq, n);
+  adamw_k<false><<<ge_blocks(n, 256 * 4, 8192), 256, 0, ge_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, wd_mask, hyper, gnorm_sq, n,
+                                                                             nullptr);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+extern "C" int ge_adamw_step_shadow(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* wd_mask,
+                                    const float* hyper, const double* gnorm_sq, long n, void* shadow_bf16, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !wd_mask || !hyper || !shadow_bf16 || n < 0) return GE_ERR_BAD_ARG;
+  if (n == 0) return GE_OK;
+  adamw_k<true><<<ge_blocks(n, 256 * 4, 8192), 256, 0, ge_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, wd_mask, hyper, gnorm_sq, n,
+                                                                            (bf16_t*)shadow_bf16);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -645,3 +645,56 @@ extern "C" int ge_add_rows(const void* x, const float* pos, void* out, int B, lo
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
+
+// ============================================================================ column sums of a token matrix
+// out[c] (+)= sum_r x[r, c]: the bias gradient of every token Linear (dY is (tokens, C) with 5e4 - 8e5 rows), which ATen runs as a
+// generic reduce_kernel.  Columns are split into chunks of <= 256 16-byte lanes (blockIdx.y) so that any C % VN == 0 is served.
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_k(const T* __restrict__ x, double* __restrict__ ws, int C, long R, int lpr, int rpi) {
+  constexpr int VN = V8<T>::N;
+  const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
+  const int c0 = (blockIdx.y * lpr + lane) * VN;
+  float acc[1][VN];
+#pragma unroll
+  for (int v = 0; v < VN; ++v) acc[0][v] = 0.f;
+  if (rs < rpi)
+    for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
+      float v[VN];
+      V8<T>::ld(x + r * C + c0, v);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) acc[0][k] += v[k];
+    }
+  nh_col_commit<1, VN>(acc, ws, C, lpr, rpi, c0);
+}
+__global__ void __launch_bounds__(256) colsum_finalize_k(const double* __restrict__ ws, float* __restrict__ out, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  out[c] = accumulate ? out[c] + (float)ws[c] : (float)ws[c];
+}
+template <typename T>
+static int colsum_launch(const void* x, long R, int C, float* out, double* ws, int accumulate, hipStream_t s) {
+  constexpr int VN = V8<T>::N;
+  if (C % VN || !nh_aligned(x)) return GE_ERR_UNSUPPORTED;
+  const int lanes = C / VN;
+  int lpr = lanes < NH_MAXLANES ? lanes : NH_MAXLANES;
+  while (lanes % lpr) --lpr;                                           // largest divisor of the lane count that fits a workgroup
+  const int rpi = NH_MAXLANES / lpr, chunks = lanes / lpr;
+  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * C, s);
+  if (he != hipSuccess) return (int)he;
+  unsigned gx = nh_grid_rows(R, rpi);
+  if (chunks > 1) gx = (gx + chunks - 1) / chunks;
+  if (R > 0) {
+    colsum_k<T><<<dim3(gx ? gx : 1, chunks), 256, 0, s>>>((const T*)x, ws, C, R, lpr, rpi);
+    GE_LAUNCH_CHECK();
+  }
+  colsum_finalize_k<<<(C + 255) / 256, 256, 0, s>>>(ws, out, C, accumulate);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+// x (R, C) row-major f32 / bf16 -> out (C) f32; workspace: C doubles (zeroed here); accumulate != 0: out += sums
+extern "C" int ge_colsum(const void* x, long R, int C, float* out, double* workspace, int accumulate, int dtype, void* stream) {
+  if (!x || !out || !workspace || R < 0 || C <= 0) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return colsum_launch<float>(x, R, C, out, workspace, accumulate, ge_stream(stream));
+  if (dtype == GE_BF16) return colsum_launch<bf16_t>(x, R, C, out, workspace, accumulate, ge_stream(stream));
+  return GE_ERR_UNSUPPORTED;
+}

@@ -63,6 +63,7 @@ SIGNATURES = {
     'ge_concat_rows_fwd': (_i, [_vp, _l, _l, _vp, _vp, _vp, _l, _i, _i, _i, _f, _u64, _i, _vp]),
     'ge_slice_rows_drop': (_i, [_vp, _vp, _l, _i, _i, _i, _f, _u64, _i, _vp]),
     'ge_add_rows': (_i, [_vp, _vp, _vp, _i, _l, _i, _i, _vp]),
+    'ge_colsum': (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _vp]),
     'ge_aug_load': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_depth': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_resize': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     'ge_silog_bwd': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _l, _vp]),
     'ge_sumsq': (_i, [_vp, _l, _vp, _vp]),
     'ge_adamw_step': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    'ge_adamw_step_shadow': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp]),
 }
 
 _lib = None

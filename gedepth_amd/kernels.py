@@ -558,6 +558,26 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dwb[0], dwb[1], None, None
 
 
+_COLSUM_WS = {}
+
+
+def colsum(x):
+    """(R, C) f32 / bf16 -> (C,) f32 column sums (bias gradient of a token Linear) in one streaming pass."""
+    R, C = x.shape
+    vn = 4 if x.dtype == _f32 else 8
+    if x.dtype not in (_f32, torch.bfloat16) or C % vn or not x.is_contiguous() or x.data_ptr() % 16:
+        note_fallback('colsum', f'C={C} dtype={x.dtype}')
+        return x.sum(0, dtype=_f32)
+    key = (x.device, C, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _COLSUM_WS.get(key)
+    if ws is None:                                      # launches are stream-ordered: one workspace per (width, stream) is enough
+        ws = _COLSUM_WS[key] = torch.empty(C, device=x.device, dtype=torch.float64)
+    out = torch.empty(C, device=x.device, dtype=_f32)
+    PROFILER.run(f'colsum[{R}x{C} {_tag(x)}]', x.numel() * _es(x), lambda: hip.check(
+        hip.lib().ge_colsum(hip.ptr(x, name='x'), R, C, hip.ptr(out), hip.ptr(ws), 0, hip.dtype_code(x), hip.stream()), 'ge_colsum'))
+    return out
+
+
 def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     """LayerNorm over the last dim; x f32/bf16, statistics f32, output ``out_dtype`` (default: x.dtype)."""
     return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype or x.dtype)

@@ -124,8 +124,9 @@ class _LinearTokens(torch.autograd.Function):
     def forward(ctx, x, weight, bias, splits):
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
         with torch.autocast('cuda', enabled=False):
-            xc, wc = x.to(dt), weight.to(dt)
-            y = F.linear(xc, wc, None if bias is None else bias.to(dt))
+            from .optim import lowp
+            xc, wc = x.to(dt), lowp(weight, dt)
+            y = F.linear(xc, wc, None if bias is None else lowp(bias, dt))
         ctx.save_for_backward(xc, wc)
         ctx.meta = (splits, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -149,16 +150,21 @@ class _LinearTokens(torch.autograd.Function):
                 else:
                     dw = (dy2.t() @ x2).to(w_dtype)
             if b_dtype is not None and ctx.needs_input_grad[2]:
-                db = dy2.sum(0, dtype=torch.float32).to(b_dtype)
+                if dy2.shape[1] % (4 if dy2.dtype == torch.float32 else 8) == 0:      # 16-byte channel vectors: one streaming pass
+                    from .. import kernels
+                    db = kernels.colsum(dy2 if dy2.is_contiguous() else dy2.contiguous()).to(b_dtype)
+                else:                                                                 # e.g. the 2-wide reference-point Linear of HAHI
+                    db = dy2.sum(0, dtype=torch.float32).to(b_dtype)
         return dx, dw, db, None
 
 
 def linear_tokens(x, weight, bias=None):
     """``F.linear`` for token matrices: split-K weight gradient when the token count is large (see _LinearTokens)."""
-    splits = _split_k(x.numel() // x.shape[-1]) if (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad) else 0
-    if not splits or x.dtype not in (torch.float32, torch.bfloat16):
+    if not (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad) or x.dtype not in (torch.float32, torch.bfloat16) or x.dim() < 2 or x.numel() == 0:
         return F.linear(x, weight, bias)
-    return _LinearTokens.apply(x, weight, bias, splits)
+    # every training-mode token Linear takes this route (splits == 0: plain library dW): weights come from the optimizer's bf16
+    # shadow arena instead of a cast kernel each, and the bias gradient is one column-sum kernel
+    return _LinearTokens.apply(x, weight, bias, _split_k(x.numel() // x.shape[-1]))
 
 
 class Linear(nn.Linear):

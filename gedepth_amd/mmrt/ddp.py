@@ -40,6 +40,8 @@ class FlatDDP(nn.Module):
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         if self.active and broadcast:
             dist.broadcast(arena.flat_param, src=0, group=process_group)        # C2: rank-0 state -> all
+            if hasattr(arena, 'refresh_shadow'):
+                arena.refresh_shadow(copy=True)                                 # the bf16 shadow follows the broadcast values
             for b in module.buffers():
                 if b.is_floating_point():
                     dist.broadcast(b, src=0, group=process_group)
@@ -80,7 +82,9 @@ class FlatDDP(nn.Module):
         return hook
 
     def _launch(self, b):
-        lo, hi, _ = self.buckets[b]
+        lo, hi, members = self.buckets[b]
+        if hasattr(self.arena, 'collect'):
+            self.arena.collect(members)                       # gradients autograd handed over -> this bucket's arena slice
         buf = self.arena.flat_grad[lo:hi]
         if self.grad_dtype is not None:                       # reduced-precision exchange through a staging buffer
             stage = buf.to(self.grad_dtype)
@@ -99,6 +103,8 @@ class FlatDDP(nn.Module):
     def finish(self):
         """Call after backward, before the optimizer: launches what is left, waits for all collectives."""
         if not self.active:
+            if hasattr(self.arena, 'collect'):
+                self.arena.collect()
             return
         while self._next < len(self.buckets):            # parameters without a gradient this step, or overlap off
             self._launch(self._next)

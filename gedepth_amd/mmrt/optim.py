@@ -19,7 +19,11 @@ from .. import hip
 class GradArena:
     """Flat parameter / gradient storage; ``param.data`` and ``param.grad`` become views into it."""
 
-    def __init__(self, params, align=64):
+    def __init__(self, params, align=64, adopt=None):
+        """``adopt``: let autograd hand over the gradient tensors it produces (``p.grad = None`` at ``zero_grad``; the engine then
+        *assigns* instead of launching one fp32 add per parameter into a zeroed slice — 297 launches per step for Swin-T) and
+        bring them into the arena with a few multi-tensor copies (``collect``): per bucket as soon as it is complete under
+        FlatDDP, otherwise at the optimizer step.  Default: on for HIP tensors."""
         self.params = [p for p in params if p.requires_grad]
         assert self.params, 'no trainable parameters'
         dev, dt = self.params[0].device, torch.float32
@@ -31,11 +35,14 @@ class GradArena:
         self.numel = n
         self.flat_param = torch.zeros(n, device=dev, dtype=dt)
         self.flat_grad = torch.zeros(n, device=dev, dtype=dt)
+        self.views = []
         for p, off in zip(self.params, self.offsets):
             view = self._view(self.flat_param, off, p)
             view.copy_(p.data)
             p.data = view
             p.grad = self._view(self.flat_grad, off, p)
+            self.views.append(p.grad)
+        self.adopt = (dev.type == 'cuda') if adopt is None else bool(adopt)
 
     @staticmethod
     def _view(flat, off, p):
@@ -48,20 +55,67 @@ class GradArena:
         return chunk.view_as(p)
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        if self.adopt:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat_grad.zero_()
+
+    def collect(self, indices=None):
+        """Make the arena hold the current gradients of the parameters ``indices`` (all by default) and point ``p.grad`` back at
+        its slice: tensors autograd assigned are copied in (multi-tensor copy), slices of parameters without a gradient are
+        zeroed, slices autograd accumulated into directly are left alone.  Idempotent."""
+        src, dst, empty = [], [], []
+        for i in (range(len(self.params)) if indices is None else indices):
+            p, v = self.params[i], self.views[i]
+            g = p.grad
+            if g is None:
+                empty.append(v)
+            elif g is not v and g.data_ptr() != v.data_ptr():
+                src.append(g.detach())
+                dst.append(v)
+            p.grad = v
+        with torch.no_grad():
+            if empty:
+                torch._foreach_zero_(empty)
+            if src:
+                torch._foreach_copy_(dst, src)
+
+    # ---- bf16 shadow of the parameters (what the autocast forward reads) ----
+    def enable_shadow(self):
+        """Allocate a bf16 copy of the parameter arena and hang a view of it on every parameter (``p._ge_lp``).  The fused
+        optimizer keeps it current; consumers go through ``lowp(p, dtype)``, which checks the tensor version so that any
+        other write to the parameter (checkpoint load, broadcast, init) falls back to a cast until the next refresh."""
+        if getattr(self, 'flat_shadow', None) is None:
+            self.flat_shadow = torch.zeros(self.numel, device=self.flat_param.device, dtype=torch.bfloat16)
+            for p, off in zip(self.params, self.offsets):
+                p._ge_lp = self._view(self.flat_shadow, off, p)
+                p._ge_lp_version = -1
+        return self.flat_shadow
+
+    def refresh_shadow(self, copy=True):
+        """Mark the shadow current (after the optimizer kernel wrote it) or rebuild it from the fp32 arena (``copy``)."""
+        if getattr(self, 'flat_shadow', None) is None:
+            return
+        if copy:
+            self.flat_shadow.copy_(self.flat_param)
+        for p in self.params:
+            p._ge_lp_version = p._version
 
     def reattach(self):
         """Copy externally-assigned ``.grad`` tensors into the arena and re-point them (tests / foreign code)."""
-        for p, off in zip(self.params, self.offsets):
-            view = self._view(self.flat_grad, off, p)
-            if p.grad is None:
-                view.zero_()
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
+        self.collect()
 
     def slices(self):
         return [(off, p.numel()) for p, off in zip(self.params, self.offsets)]
+
+
+def lowp(p, dtype):
+    """``p.to(dtype)`` served from the optimizer's bf16 shadow arena when it is current (no kernel), else a cast."""
+    s = getattr(p, '_ge_lp', None)
+    if s is not None and s.dtype == dtype and p._ge_lp_version == p._version:
+        return s
+    return p.to(dtype)
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -70,7 +124,7 @@ class FusedAdamW(torch.optim.Optimizer):
     All groups must share lr / betas / eps; ``weight_decay`` may be the base value or 0 per group
     (that is what ``paramwise_cfg.custom_keys`` with ``decay_mult=0`` produces)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0, bf16_shadow=True):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         wds = sorted({g['weight_decay'] for g in self.param_groups})
@@ -96,6 +150,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # ring of pinned staging buffers: the H2D copy of the step scalars never blocks the host
         self._ring = [(torch.zeros(10, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
         self.gnorm_sq = torch.zeros(1, device=dev, dtype=torch.float64)
+        if bf16_shadow:                            # 2 B / parameter: the autocast forward reads weights from here, no per-tensor casts
+            self.arena.enable_shadow()
+            self.arena.refresh_shadow(copy=True)
 
     def sync_grads_from_params(self):
         self.arena.reattach()
@@ -123,11 +180,19 @@ class FusedAdamW(torch.optim.Optimizer):
         self.hyper.copy_(host, non_blocking=True)
         ev.record()
         lib, a = hip.lib(), self.arena
+        a.collect()                            # gradients autograd handed over (not yet brought in by FlatDDP) -> arena
         self.gnorm_sq.zero_()
         hip.check(lib.ge_sumsq(hip.ptr(a.flat_grad), a.numel, hip.ptr(self.gnorm_sq), hip.stream()), 'ge_sumsq')
-        hip.check(lib.ge_adamw_step(hip.ptr(a.flat_param), hip.ptr(a.flat_grad), hip.ptr(self.exp_avg), hip.ptr(self.exp_avg_sq),
-                                    hip.ptr(self.wd_mask), hip.ptr(self.hyper), hip.ptr(self.gnorm_sq), a.numel,
-                                    hip.stream()), 'ge_adamw_step')
+        shadow = getattr(a, 'flat_shadow', None)
+        if shadow is None:
+            hip.check(lib.ge_adamw_step(hip.ptr(a.flat_param), hip.ptr(a.flat_grad), hip.ptr(self.exp_avg), hip.ptr(self.exp_avg_sq),
+                                        hip.ptr(self.wd_mask), hip.ptr(self.hyper), hip.ptr(self.gnorm_sq), a.numel,
+                                        hip.stream()), 'ge_adamw_step')
+        else:
+            hip.check(lib.ge_adamw_step_shadow(hip.ptr(a.flat_param), hip.ptr(a.flat_grad), hip.ptr(self.exp_avg),
+                                               hip.ptr(self.exp_avg_sq), hip.ptr(self.wd_mask), hip.ptr(self.hyper),
+                                               hip.ptr(self.gnorm_sq), a.numel, hip.ptr(shadow), hip.stream()), 'ge_adamw_step_shadow')
+            a.refresh_shadow(copy=False)
 
     def state_dict(self):
         """``torch.optim.AdamW`` layout (what mmcv's CheckpointHook stores and the reference's checkpoints hold):

@@ -42,6 +42,7 @@ def use_miopen_find_db(path=MIOPEN_DB):
     workloads from the db (+6 % step rate) instead of timing all solvers for ~5 minutes on a fresh machine.  The db is
     copied to a scratch directory because MIOpen appends to it while running."""
     import shutil
+    skip_naive_conv_solvers()
     if os.environ.get('MIOPEN_USER_DB_PATH'):
         return True                                    # the user manages the db
     files = [f for f in (os.listdir(path) if os.path.isdir(path) else []) if f.endswith('db.txt')]
@@ -74,3 +75,11 @@ def use_miopen_find_db(path=MIOPEN_DB):
         os.replace(tmp, target)
     os.environ['MIOPEN_USER_DB_PATH'] = dst
     return True
+
+
+def skip_naive_conv_solvers():
+    """Keep MIOpen's reference ('naive') direct convolutions out of the find step.  On a machine without a kernel cache MIOpen
+    re-times every applicable solver per problem whatever the find-db says; the naive NHWC kernels take 0.1 - 7 s per call (150 s of a
+    160 s start-up on MI355X, profiles/README.md) and never win.  They stay available if the user sets the variables."""
+    for d in ('FWD', 'BWD', 'WRW'):
+        os.environ.setdefault(f'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{d}', '0')

@@ -281,6 +281,8 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
  *   torch.cat([to_map(dropout(tokens)) + identity, fmap], 1) of necks/hahi.py:326-346 on channels-last maps.
  * ge_slice_rows_drop: its backward w.r.t. a: d_a (rows, Ca) = d_out[:, off_a : off_a + Ca] * dropout.
  * ge_add_rows: out (B, N, C) = x + pos (N, C) f32 broadcast over the batch (query + query_pos, hahi.py:303-306).
+ * ge_colsum: out (C) f32 (+)= column sums of x (R, C) f32 / bf16 — the bias gradient of the token Linears
+ *   (depthformer_swin.py:193-221,451-459; hahi.py value / offset / attention / output projections); workspace: C doubles.
  */
 int ge_bn_act_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
                        float* running_mean, float* running_var, void* workspace, long rows, int C, float eps,
@@ -301,6 +303,7 @@ int ge_concat_rows_fwd(const void* a, long rows_per_batch, long a_batch_stride, 
 int ge_slice_rows_drop(const void* d_out, void* d_a, long rows, int Ca, int Co, int off_a, float p_drop,
                        unsigned long long seed, int dtype, void* stream);
 int ge_add_rows(const void* x, const float* pos, void* out, int B, long N, int C, int dtype, void* stream);
+int ge_colsum(const void* x, long R, int C, float* out, double* workspace, int accumulate, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-side data pipeline of the training samples (csrc/aug.hip).  Planar f32 maps (C, H, W); each
@@ -360,6 +363,10 @@ int ge_silog_bwd(const float* pred, const float* gt, float eps, const float* coe
 int ge_sumsq(const float* x, long n, double* out, void* stream);
 int ge_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* wd_mask,
                   const float* hyper, const double* gnorm_sq, long n, void* stream);
+/* same step, and the updated parameters rounded to bf16 (nearest-even) into `shadow_bf16` (n elements): the low-precision
+ * weights the next autocast forward reads, instead of one cast kernel per tensor and step. */
+int ge_adamw_step_shadow(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* wd_mask,
+                         const float* hyper, const double* gnorm_sq, long n, void* shadow_bf16, void* stream);
 
 #ifdef __cplusplus
 }

@@ -56,7 +56,7 @@ def main():
     # order), and AdamW turns a sign flip of a noise-level gradient into a full +-lr step — so the exchanged GRADIENT of the
     # first step and the losses are compared, not the parameters
     rel = ((ga - gb).double().norm() / gb.double().norm()).item()
-    assert rel <= 1e-5, rel
+    assert rel <= 1e-4, rel             # measured 5e-6 ... 1.3e-5 run to run (atomics order); a broken exchange is O(1)
     assert abs(la[0] - lb[0]) <= 1e-6 * abs(lb[0]) and abs(la[1] - lb[1]) <= 1e-3 * abs(lb[1]), (la, lb)
     dist.destroy_process_group()
     print('RCCL_DDP_OK', la, rel)

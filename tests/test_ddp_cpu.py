@@ -46,8 +46,8 @@ class Toy(nn.Module):
 class ArenaSGD:
     """Minimal optimizer over a GradArena for the CPU tests (the product's FusedAdamW is MI355X-only)."""
 
-    def __init__(self, model, lr=0.1):
-        self.arena = GradArena(model.parameters())
+    def __init__(self, model, lr=0.1, adopt=None):
+        self.arena = GradArena(model.parameters(), adopt=adopt)
         self.defaults = dict(lr=lr)
         self.param_groups = [dict(lr=lr, params=self.arena.params)]
 
@@ -55,6 +55,7 @@ class ArenaSGD:
         self.arena.zero_grad()
 
     def step(self):
+        self.arena.collect()
         self.arena.flat_param.add_(self.arena.flat_grad, alpha=-self.param_groups[0]['lr'])
 
     def state_dict(self):
@@ -64,12 +65,12 @@ class ArenaSGD:
         pass
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, adopt=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
     model = Toy()
-    opt = ArenaSGD(model)
+    opt = ArenaSGD(model, adopt=adopt)
     ddp = FlatDDP(model, opt.arena, bucket_mb=0.0005)  # ~130 floats per bucket -> several buckets
     assert len(ddp.buckets) >= 3
     g = torch.Generator().manual_seed(0)
@@ -93,9 +94,12 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_flat_ddp_gloo_world2(tmp_path):
+@pytest.mark.parametrize('adopt', [False, True])
+def test_flat_ddp_gloo_world2(tmp_path, adopt):
+    """``adopt``: gradients handed over by autograd and copied into the arena per bucket (the MI355X default) vs accumulated
+    straight into the arena slices — the exchanged result must be the same."""
     port = free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), adopt), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f'r{i}.pt', weights_only=False) for i in range(2))
     # broadcast: both ranks hold rank 0's initial parameters
     for k in r0['params']:
@@ -350,3 +354,32 @@ def test_multi_gpu_test_returns_dataset_order_on_rank0(tmp_path):
     r1 = torch.load(tmp_path / 'eval1.pt', weights_only=False)
     assert r1 is None
     assert [v for v, _ in r0] == [0.0, 1.0, 2.0, 3.0, 4.0] and [i for _, i in r0] == [0, 1, 2, 3, 4]
+
+
+def test_grad_arena_adopts_autograd_gradients():
+    """adopt mode: zero_grad drops the .grad references, backward assigns fresh tensors, collect() brings them into the arena
+    (zeros for parameters that got no gradient), a second collect is a no-op, and accumulation over two backward passes
+    before the step still sums."""
+    torch.manual_seed(0)
+    model = Toy()
+    extra = torch.nn.Parameter(torch.ones(3))                     # never used in the loss: its slice must read zero
+    arena = GradArena(list(model.parameters()) + [extra], adopt=True)
+    arena.flat_grad.fill_(7.0)                                    # stale content of a previous step
+    arena.zero_grad()
+    assert all(p.grad is None for p in arena.params)
+    x, y = torch.randn(4, 8), torch.randn(4, 1)
+    (model(x) - y).pow(2).mean().backward()
+    handed = [p.grad for p in arena.params[:-1]]
+    assert all(g is not None and g.data_ptr() != v.data_ptr() for g, v in zip(handed, arena.views))
+    (model(x) - y).pow(2).mean().backward()                       # accumulates into the handed-over tensors
+    arena.collect()
+    ref = Toy()
+    ref.load_state_dict(model.state_dict())
+    (2 * (ref(x) - y).pow(2).mean()).backward()
+    for i, (p, q) in enumerate(zip(arena.params[:-1], ref.parameters())):
+        assert p.grad.data_ptr() == arena.views[i].data_ptr()
+        assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-8)
+    assert bool((arena.views[-1] == 0).all())
+    before = arena.flat_grad.clone()
+    arena.collect()
+    assert torch.equal(before, arena.flat_grad)

@@ -1177,3 +1177,49 @@ def test_nhwc_token_map_glue_matches_nchw(dev, dtype, tokens_first):
     assert all(v == 0.0 or abs(v - 1 / 0.75) < 1e-2 for v in vals) and abs(part.float().mean().item() - 1.0) < 0.05
     out.sum().backward()
     assert torch.equal((tk.grad.float() > 0), (part.permute(0, 2, 3, 1).reshape(B, H * W, C).float() > 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,C,dt', [(197120, 96, 'bf16'), (3080, 3072, 'bf16'), (1001, 2304, 'bf16'), (777, 100, 'f32'), (5, 8, 'bf16'),
+                                     (49280, 1536, 'f32'), (33, 4104, 'bf16')])
+def test_colsum_vs_float64(dev, R, C, dt):
+    """Bias gradient of the token Linears: column sums in one pass, fp32 per thread + fp64 across workgroups."""
+    from gedepth_amd import kernels
+    dtype = torch.bfloat16 if dt == 'bf16' else torch.float32
+    x = (torch.randn(R, C, device=dev) * 3 + 0.25).to(dtype)
+    got = kernels.colsum(x)
+    ref = x.double().sum(0)
+    scale = x.double().abs().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (C,)
+    assert float(((got.double() - ref).abs() / scale).max()) < 2e-6
+    assert not [k for k in kernels.FALLBACKS if k.startswith('colsum')]
+
+
+@pytest.mark.gpu
+def test_fused_adamw_bf16_shadow_tracks_parameters(dev):
+    """The optimizer kernel writes the bf16 copy the autocast forward reads; ``lowp`` serves it only while it is current."""
+    from gedepth_amd.mmrt.optim import FusedAdamW, lowp
+    torch.manual_seed(3)
+    ps = [torch.randn(s, device=dev).requires_grad_(True) for s in ((33, 7), (129,), (4, 3, 3, 3))]
+    opt = FusedAdamW([dict(params=ps, weight_decay=0.01)], lr=1e-2, max_grad_norm=1.0)
+    for p in ps:                                                 # built at construction
+        assert lowp(p, torch.bfloat16).data_ptr() == p._ge_lp.data_ptr()
+        assert torch.equal(p._ge_lp, p.detach().to(torch.bfloat16))
+        assert lowp(p, torch.float32) is p
+    for _ in range(3):
+        for p in ps:
+            p.grad.copy_(torch.randn_like(p))
+        opt.step()
+    for p in ps:
+        got = lowp(p, torch.bfloat16)
+        assert got.data_ptr() == p._ge_lp.data_ptr() and torch.equal(got, p.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        ps[0].copy_(torch.ones_like(ps[0]))                      # a foreign write (checkpoint load): the shadow is stale ...
+    stale = lowp(ps[0], torch.bfloat16)
+    assert stale.data_ptr() != ps[0]._ge_lp.data_ptr() and bool((stale == 1).all())      # ... so a cast is served
+    ps[0].grad.zero_()
+    opt.step()                                                   # the next step makes it current again
+    assert lowp(ps[0], torch.bfloat16).data_ptr() == ps[0]._ge_lp.data_ptr()
+    assert torch.equal(ps[0]._ge_lp, ps[0].detach().to(torch.bfloat16))
+    plain = FusedAdamW([dict(params=[torch.randn(5, device=dev).requires_grad_(True)])], lr=1e-2, bf16_shadow=False)
+    assert getattr(plain.arena, 'flat_shadow', None) is None
