@@ -18,10 +18,13 @@
 #define NH_MAXLANES 256
 
 // ---------------------------------------------------------------------------------------------- column sums
-// K column sums of f_k(row element) over a (R, C) matrix: thread = (row slot, channel vector); fp32 per thread over its rows,
-// LDS across the row slots of a workgroup, one fp64 atomic per (workgroup, channel) into ws[k * C + c].
+// K column sums of f_k(row element) over a (R, C) matrix: thread = (row slot, channel vector); fp32 per thread over its rows, LDS
+// tree across the row slots of a workgroup, one fp32 partial per (workgroup, k, channel) into `partial`, then
+// nh_partials_reduce_k sums the partials of all workgroups in fp64 into ws[k * C + c].  No atomics: same-address fp64 atomics
+// serialise in L2 at ~0.1 us each (512 workgroups x C channels cost 50-100 us whatever the matrix size; the first version).
+#define NH_MAXBLOCKS 1024
 template <int K, int VN>
-__device__ __forceinline__ void nh_col_commit(float (&acc)[K][VN], double* __restrict__ ws, int C, int lpr, int rpi, int c0) {
+__device__ __forceinline__ void nh_col_commit(float (&acc)[K][VN], float* __restrict__ partial, int C, int lpr, int rpi, int c0) {
   __shared__ float sm[K][NH_MAXLANES][VN];
   const int t = threadIdx.x, rs = t / lpr;
 #pragma unroll
@@ -42,22 +45,49 @@ __device__ __forceinline__ void nh_col_commit(float (&acc)[K][VN], double* __res
   }
   if (t < lpr) {
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int k = 0; k < K; ++k) {
+      float* o = partial + ((long)blockIdx.x * K + k) * C + c0;
 #pragma unroll
-      for (int v = 0; v < VN; ++v) atomicAdd(&ws[(long)k * C + c0 + v], (double)sm[k][t][v]);
+      for (int v = 0; v < VN; v += 4) *(float4*)(o + v) = make_float4(sm[k][t][v], sm[k][t][v + 1], sm[k][t][v + 2], sm[k][t][v + 3]);
+    }
   }
 }
-// few, long-running workgroups: every one of them ends in C same-address fp64 atomics, which serialise in L2
+// ws[kc] = sum over nb workgroups of partial[b * KC + kc], fp64; 32 columns x 8 workgroup slices per 256 threads
+__global__ void __launch_bounds__(256) nh_partials_reduce_k(const float* __restrict__ partial, double* __restrict__ ws, int KC, int nb) {
+  __shared__ double sm[8][32];
+  const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int kc = blockIdx.x * 32 + j;
+  double a = 0.0;
+  if (kc < KC) {
+#pragma unroll 8
+    for (int b = sl; b < nb; b += 8) a += (double)partial[(long)b * KC + kc];
+  }
+  sm[sl][j] = a;
+  __syncthreads();
+  if (sl == 0 && kc < KC) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) a += sm[q][j];
+    ws[kc] = a;
+  }
+}
 static inline unsigned nh_grid_rows(long R, int rpi) {
-  long b = (R + (long)rpi * 16 - 1) / ((long)rpi * 16);
+  long b = (R + (long)rpi * 8 - 1) / ((long)rpi * 8);
   if (b < 1) b = 1;
-  if (b > 512) b = 512;
+  if (b > NH_MAXBLOCKS) b = NH_MAXBLOCKS;
   return (unsigned)b;
+}
+// workspace of the column-sum users: K*C doubles (sums) | 3*C floats (BatchNorm coefficients) | NH_MAXBLOCKS*K*C floats (partials)
+extern "C" size_t ge_nhwc_workspace(int C, int K) {
+  return (size_t)C * ((size_t)K * sizeof(double) + 3 * sizeof(float) + (size_t)NH_MAXBLOCKS * K * sizeof(float));
+}
+static inline float* nh_partials(void* workspace, int C, int K) { return (float*)((char*)workspace + (size_t)C * (K * sizeof(double) + 3 * sizeof(float))); }
+static inline void nh_reduce_launch(void* workspace, int C, int K, unsigned nb, hipStream_t s) {
+  nh_partials_reduce_k<<<(K * C + 31) / 32, 256, 0, s>>>(nh_partials(workspace, C, K), (double*)workspace, K * C, (int)nb);
 }
 
 // ============================================================================ BatchNorm2d (training) + (Leaky)ReLU
 template <typename T>
-__global__ void __launch_bounds__(256) bn_stats_nhwc_k(const T* __restrict__ x, double* __restrict__ ws, int C, long R, int lpr, int rpi) {
+__global__ void __launch_bounds__(256) bn_stats_nhwc_k(const T* __restrict__ x, float* __restrict__ ws, int C, long R, int lpr, int rpi) {
   constexpr int VN = V8<T>::N;
   const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
   const int c0 = lane * VN;
@@ -94,7 +124,7 @@ __global__ void __launch_bounds__(256) bn_apply_nhwc_k(const T* __restrict__ x, 
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_stats_nhwc_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                           double* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
+                                                           float* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
   constexpr int VN = V8<T>::N;
   const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
   const int c0 = lane * VN;
@@ -195,7 +225,7 @@ static inline unsigned nh_grid_apply(long R, int rpi) {           // ~4 rows per
   return (unsigned)b;
 }
 
-// workspace: same layout / size as ge_bn_workspace(C): double[2C] sums + float[3C] coefficients
+// workspace: ge_nhwc_workspace(C, 2) bytes: double[2C] sums | float[3C] coefficients | partials
 template <typename T>
 static int bn_nhwc_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
                               float* running_mean, float* running_var, void* workspace, long R, int C, float eps, float momentum,
@@ -204,9 +234,10 @@ static int bn_nhwc_fwd_launch(const void* x, const float* gamma, const float* be
   if (!nh_geom<T>(C, lpr, rpi) || !nh_aligned(x, y)) return GE_ERR_UNSUPPORTED;
   double* ws = (double*)workspace;
   float* coef = (float*)(ws + 2 * C);
-  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s);
-  if (he != hipSuccess) return (int)he;
-  bn_stats_nhwc_k<T><<<nh_grid_rows(R, rpi), 256, 0, s>>>((const T*)x, ws, C, R, lpr, rpi);
+  const unsigned nb = nh_grid_rows(R, rpi);
+  bn_stats_nhwc_k<T><<<nb, 256, 0, s>>>((const T*)x, nh_partials(workspace, C, 2), C, R, lpr, rpi);
+  GE_LAUNCH_CHECK();
+  nh_reduce_launch(workspace, C, 2, nb, s);
   GE_LAUNCH_CHECK();
   bn_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, beta, save_mean, save_rstd, running_mean, running_var, coef, C, (double)R, eps, momentum);
   GE_LAUNCH_CHECK();
@@ -222,9 +253,11 @@ static int bn_nhwc_bwd_launch(const void* dy, const void* y, const void* x, cons
   if (!nh_geom<T>(C, lpr, rpi) || !nh_aligned(dy, y, x, dx)) return GE_ERR_UNSUPPORTED;
   double* ws = (double*)workspace;
   float* coef = (float*)(ws + 2 * C);
-  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s);
-  if (he != hipSuccess) return (int)he;
-  bn_bwd_stats_nhwc_k<T><<<nh_grid_rows(R, rpi), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, ws, C, R, lpr, rpi, slope);
+  const unsigned nb = nh_grid_rows(R, rpi);
+  bn_bwd_stats_nhwc_k<T><<<nb, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, nh_partials(workspace, C, 2), C, R, lpr,
+                                            rpi, slope);
+  GE_LAUNCH_CHECK();
+  nh_reduce_launch(workspace, C, 2, nb, s);
   GE_LAUNCH_CHECK();
   bn_bwd_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, save_rstd, dgamma, dbeta, coef, C, (double)R);
   GE_LAUNCH_CHECK();
@@ -271,7 +304,7 @@ __global__ void __launch_bounds__(256) bias_act_nhwc_fwd_k(T* __restrict__ x, co
 // dx = dy * act'(y); d_bias (fp64 workspace, C doubles, zeroed by the launcher) = column sums of dx
 template <typename T>
 __global__ void __launch_bounds__(256) bias_act_nhwc_bwd_k(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
-                                                           double* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
+                                                           float* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
   constexpr int VN = V8<T>::N;
   const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
   const int c0 = lane * VN;
@@ -309,24 +342,28 @@ extern "C" int ge_bias_act_nhwc_fwd(void* x, const float* bias, long rows, int C
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
-// workspace: C doubles
+// workspace: ge_nhwc_workspace(C, 1) bytes
 extern "C" int ge_bias_act_nhwc_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, long rows, int C, float slope,
                                     int dtype, void* stream) {
   if (!dy || !y || !dx || !dbias || !workspace || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
   int lpr, rpi;
   hipStream_t s = ge_stream(stream);
   double* ws = (double*)workspace;
-  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * C, s);
-  if (he != hipSuccess) return (int)he;
+  float* part = nh_partials(workspace, C, 1);
+  unsigned nb = 1;
   if (dtype == GE_F32) {
     if (!nh_geom<float>(C, lpr, rpi) || !nh_aligned(dy, y, dx)) return GE_ERR_UNSUPPORTED;
-    bias_act_nhwc_bwd_k<float><<<nh_grid_rows(rows, rpi), 256, 0, s>>>((const float*)dy, (const float*)y, (float*)dx, ws, C, rows, lpr, rpi, slope);
+    nb = nh_grid_rows(rows, rpi);
+    bias_act_nhwc_bwd_k<float><<<nb, 256, 0, s>>>((const float*)dy, (const float*)y, (float*)dx, part, C, rows, lpr, rpi, slope);
   } else if (dtype == GE_BF16) {
     if (!nh_geom<bf16_t>(C, lpr, rpi) || !nh_aligned(dy, y, dx)) return GE_ERR_UNSUPPORTED;
-    bias_act_nhwc_bwd_k<bf16_t><<<nh_grid_rows(rows, rpi), 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, ws, C, rows, lpr, rpi, slope);
+    nb = nh_grid_rows(rows, rpi);
+    bias_act_nhwc_bwd_k<bf16_t><<<nb, 256, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, part, C, rows, lpr, rpi, slope);
   } else {
     return GE_ERR_UNSUPPORTED;
   }
+  GE_LAUNCH_CHECK();
+  nh_reduce_launch(workspace, C, 1, nb, s);
   GE_LAUNCH_CHECK();
   nh_d2f_k<<<(C + 255) / 256, 256, 0, s>>>(ws, dbias, C);
   GE_LAUNCH_CHECK();
@@ -650,7 +687,7 @@ extern "C" int ge_add_rows(const void* x, const float* pos, void* out, int B, lo
 // out[c] (+)= sum_r x[r, c]: the bias gradient of every token Linear (dY is (tokens, C) with 5e4 - 8e5 rows), which ATen runs as a
 // generic reduce_kernel.  Columns are split into chunks of <= 256 16-byte lanes (blockIdx.y) so that any C % VN == 0 is served.
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_k(const T* __restrict__ x, double* __restrict__ ws, int C, long R, int lpr, int rpi) {
+__global__ void __launch_bounds__(256) colsum_k(const T* __restrict__ x, float* __restrict__ ws, int C, long R, int lpr, int rpi) {
   constexpr int VN = V8<T>::N;
   const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
   const int c0 = (blockIdx.y * lpr + lane) * VN;
@@ -672,27 +709,26 @@ __global__ void __launch_bounds__(256) colsum_finalize_k(const double* __restric
   out[c] = accumulate ? out[c] + (float)ws[c] : (float)ws[c];
 }
 template <typename T>
-static int colsum_launch(const void* x, long R, int C, float* out, double* ws, int accumulate, hipStream_t s) {
+static int colsum_launch(const void* x, long R, int C, float* out, void* ws, int accumulate, hipStream_t s) {
   constexpr int VN = V8<T>::N;
   if (C % VN || !nh_aligned(x)) return GE_ERR_UNSUPPORTED;
   const int lanes = C / VN;
   int lpr = lanes < NH_MAXLANES ? lanes : NH_MAXLANES;
   while (lanes % lpr) --lpr;                                           // largest divisor of the lane count that fits a workgroup
   const int rpi = NH_MAXLANES / lpr, chunks = lanes / lpr;
-  hipError_t he = hipMemsetAsync(ws, 0, sizeof(double) * C, s);
-  if (he != hipSuccess) return (int)he;
   unsigned gx = nh_grid_rows(R, rpi);
   if (chunks > 1) gx = (gx + chunks - 1) / chunks;
-  if (R > 0) {
-    colsum_k<T><<<dim3(gx ? gx : 1, chunks), 256, 0, s>>>((const T*)x, ws, C, R, lpr, rpi);
-    GE_LAUNCH_CHECK();
-  }
-  colsum_finalize_k<<<(C + 255) / 256, 256, 0, s>>>(ws, out, C, accumulate);
+  if (!gx) gx = 1;
+  colsum_k<T><<<dim3(gx, chunks), 256, 0, s>>>((const T*)x, nh_partials(ws, C, 1), C, R, lpr, rpi);      // R == 0: zero partials
+  GE_LAUNCH_CHECK();
+  nh_reduce_launch(ws, C, 1, gx, s);
+  GE_LAUNCH_CHECK();
+  colsum_finalize_k<<<(C + 255) / 256, 256, 0, s>>>((const double*)ws, out, C, accumulate);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
-// x (R, C) row-major f32 / bf16 -> out (C) f32; workspace: C doubles (zeroed here); accumulate != 0: out += sums
-extern "C" int ge_colsum(const void* x, long R, int C, float* out, double* workspace, int accumulate, int dtype, void* stream) {
+// x (R, C) row-major f32 / bf16 -> out (C) f32; workspace: ge_nhwc_workspace(C, 1) bytes; accumulate != 0: out += sums
+extern "C" int ge_colsum(const void* x, long R, int C, float* out, void* workspace, int accumulate, int dtype, void* stream) {
   if (!x || !out || !workspace || R < 0 || C <= 0) return GE_ERR_BAD_ARG;
   if (dtype == GE_F32) return colsum_launch<float>(x, R, C, out, workspace, accumulate, ge_stream(stream));
   if (dtype == GE_BF16) return colsum_launch<bf16_t>(x, R, C, out, workspace, accumulate, ge_stream(stream));

@@ -571,7 +571,7 @@ def colsum(x):
     key = (x.device, C, torch.cuda.current_stream(x.device).cuda_stream)
     ws = _COLSUM_WS.get(key)
     if ws is None:                                      # launches are stream-ordered: one workspace per (width, stream) is enough
-        ws = _COLSUM_WS[key] = torch.empty(C, device=x.device, dtype=torch.float64)
+        ws = _COLSUM_WS[key] = torch.empty(int(hip.lib().ge_nhwc_workspace(C, 1)), device=x.device, dtype=torch.uint8)
     out = torch.empty(C, device=x.device, dtype=_f32)
     PROFILER.run(f'colsum[{R}x{C} {_tag(x)}]', x.numel() * _es(x), lambda: hip.check(
         hip.lib().ge_colsum(hip.ptr(x, name='x'), R, C, hip.ptr(out), hip.ptr(ws), 0, hip.dtype_code(x), hip.stream()), 'ge_colsum'))
@@ -631,7 +631,7 @@ class _BNAct(torch.autograd.Function):
         w, b = _c(weight.detach().to(_f32)), _c(bias.detach().to(_f32))
         y = torch.empty_like(x)                                  # preserves the channels-last strides
         stats = torch.empty(2, C, device=x.device, dtype=_f32)
-        ws = torch.empty(int(hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
+        ws = torch.empty(int(hip.lib().ge_nhwc_workspace(C, 2) if ctx.cl else hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
         if ctx.cl:
             PROFILER.run(f'bn_act_nhwc_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 3 * x.numel() * _es(x), lambda: hip.check(
                 hip.lib().ge_bn_act_nhwc_fwd(_raw_ptr(x, 'x'), hip.ptr(w), hip.ptr(b), _raw_ptr(y, 'y'), hip.ptr(stats[0]), hip.ptr(stats[1]),
@@ -654,7 +654,7 @@ class _BNAct(torch.autograd.Function):
         N, C, H, W = x.shape
         dx = torch.empty_like(x)
         dwb = torch.empty(2, C, device=x.device, dtype=_f32)
-        ws = torch.empty(int(hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
+        ws = torch.empty(int(hip.lib().ge_nhwc_workspace(C, 2) if ctx.cl else hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
         if ctx.cl:
             dy = _cl(dy.to(x.dtype))
             PROFILER.run(f'bn_act_nhwc_bwd[{N}x{C}x{H}x{W} {_tag(x)}]', 7 * x.numel() * _es(x), lambda: hip.check(
@@ -711,7 +711,7 @@ class _BiasAct(torch.autograd.Function):
         if ctx.cl:
             dy = _cl(dy.to(y.dtype))
             db = torch.empty(C, device=y.device, dtype=_f32)
-            ws = torch.empty(C, device=y.device, dtype=torch.float64)
+            ws = torch.empty(int(hip.lib().ge_nhwc_workspace(C, 1)), device=y.device, dtype=torch.uint8)
             PROFILER.run(f'bias_act_nhwc_bwd[{N}x{C}x{H}x{W} {_tag(y)}]', 3 * y.numel() * _es(y), lambda: hip.check(
                 hip.lib().ge_bias_act_nhwc_bwd(_raw_ptr(dy, 'dy'), _raw_ptr(y, 'y'), _raw_ptr(dx, 'dx'), hip.ptr(db), hip.ptr(ws), N * H * W, C,
                                                ctx.slope, hip.dtype_code(y), hip.stream()), 'ge_bias_act_nhwc_bwd'))

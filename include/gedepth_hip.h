@@ -272,8 +272,9 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
  * (HWC, 1, WC, C) is the row matrix (rows = B*H*W, C): MIOpen's bf16 implicit-GEMM convolutions run on it without their
  * NCHW <-> NHWC batched_transpose kernels, and tokens <-> maps become views.  C must be a multiple of the 16-byte vector
  * (8 bf16 / 4 f32) and at most 256 such vectors wide, pointers 16-byte aligned; otherwise GE_ERR_UNSUPPORTED (the caller keeps NCHW).
- * ge_bn_act_nhwc_*: as ge_bn_act_* (same workspace size, ge_bn_workspace(C)); statistics are column sums.
- * ge_bias_act_nhwc_*: as ge_bias_act_*; the backward needs a workspace of C doubles, d_bias is fully written.
+ * ge_bn_act_nhwc_*: as ge_bn_act_* with a workspace of ge_nhwc_workspace(C, 2) bytes; statistics are column sums (fp32 partial per
+ *   workgroup, fp64 across workgroups, no atomics).
+ * ge_bias_act_nhwc_*: as ge_bias_act_*; the backward needs a workspace of ge_nhwc_workspace(C, 1) bytes, d_bias is fully written.
  * ge_bilinear_nhwc_*: as ge_bilinear_* on (N, H, W, C); the backward takes an optional workspace of N*Ho*Wi*C floats that
  *   enables the separable two-pass form for up-sampling factors > 3 (PE necks: 11x35 -> 176x560).
  * ge_concat_rows_fwd: out (rows, Ca+Cb) = [a * dropout + res | b] (a first) or [b | a * dropout + res]; `a` is B batches
@@ -282,7 +283,7 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
  * ge_slice_rows_drop: its backward w.r.t. a: d_a (rows, Ca) = d_out[:, off_a : off_a + Ca] * dropout.
  * ge_add_rows: out (B, N, C) = x + pos (N, C) f32 broadcast over the batch (query + query_pos, hahi.py:303-306).
  * ge_colsum: out (C) f32 (+)= column sums of x (R, C) f32 / bf16 — the bias gradient of the token Linears
- *   (depthformer_swin.py:193-221,451-459; hahi.py value / offset / attention / output projections); workspace: C doubles.
+ *   (depthformer_swin.py:193-221,451-459; hahi.py value / offset / attention / output projections); workspace: ge_nhwc_workspace(C, 1) bytes.
  */
 int ge_bn_act_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
                        float* running_mean, float* running_var, void* workspace, long rows, int C, float eps,
@@ -303,7 +304,9 @@ int ge_concat_rows_fwd(const void* a, long rows_per_batch, long a_batch_stride, 
 int ge_slice_rows_drop(const void* d_out, void* d_a, long rows, int Ca, int Co, int off_a, float p_drop,
                        unsigned long long seed, int dtype, void* stream);
 int ge_add_rows(const void* x, const float* pos, void* out, int B, long N, int C, int dtype, void* stream);
-int ge_colsum(const void* x, long R, int C, float* out, double* workspace, int accumulate, int dtype, void* stream);
+int ge_colsum(const void* x, long R, int C, float* out, void* workspace, int accumulate, int dtype, void* stream);
+/* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
+size_t ge_nhwc_workspace(int C, int K);
 
 /* ---------------------------------------------------------------------------------------------
  * Device-side data pipeline of the training samples (csrc/aug.hip).  Planar f32 maps (C, H, W); each
