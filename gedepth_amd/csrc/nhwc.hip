@@ -53,7 +53,8 @@ __device__ __forceinline__ void nh_col_commit(float (&acc)[K][VN], float* __rest
   }
 }
 // ws[kc] = sum over nb workgroups of partial[b * KC + kc], fp64; 32 columns x 8 workgroup slices per 256 threads
-__global__ void __launch_bounds__(256) nh_partials_reduce_k(const float* __restrict__ partial, double* __restrict__ ws, int KC, int nb) {
+template <typename O>
+__global__ void __launch_bounds__(256) nh_partials_reduce_k(const float* __restrict__ partial, O* __restrict__ ws, int KC, int nb, int accumulate) {
   __shared__ double sm[8][32];
   const int j = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int kc = blockIdx.x * 32 + j;
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(256) nh_partials_reduce_k(const float* __restr
   if (sl == 0 && kc < KC) {
 #pragma unroll
     for (int q = 1; q < 8; ++q) a += sm[q][j];
-    ws[kc] = a;
+    ws[kc] = accumulate ? (O)((double)ws[kc] + a) : (O)a;
   }
 }
 static inline unsigned nh_grid_rows(long R, int rpi) {
@@ -81,8 +82,12 @@ extern "C" size_t ge_nhwc_workspace(int C, int K) {
   return (size_t)C * ((size_t)K * sizeof(double) + 3 * sizeof(float) + (size_t)NH_MAXBLOCKS * K * sizeof(float));
 }
 static inline float* nh_partials(void* workspace, int C, int K) { return (float*)((char*)workspace + (size_t)C * (K * sizeof(double) + 3 * sizeof(float))); }
+// K = 1 users that want the sums as fp32 directly (bias gradients)
+static inline void nh_reduce_launch_f32(void* workspace, int C, unsigned nb, float* out, int accumulate, hipStream_t s) {
+  nh_partials_reduce_k<float><<<(C + 31) / 32, 256, 0, s>>>(nh_partials(workspace, C, 1), out, C, (int)nb, accumulate);
+}
 static inline void nh_reduce_launch(void* workspace, int C, int K, unsigned nb, hipStream_t s) {
-  nh_partials_reduce_k<<<(K * C + 31) / 32, 256, 0, s>>>(nh_partials(workspace, C, K), (double*)workspace, K * C, (int)nb);
+  nh_partials_reduce_k<double><<<(K * C + 31) / 32, 256, 0, s>>>(nh_partials(workspace, C, K), (double*)workspace, K * C, (int)nb, 0);
 }
 
 // ============================================================================ BatchNorm2d (training) + (Leaky)ReLU
@@ -322,10 +327,6 @@ __global__ void __launch_bounds__(256) bias_act_nhwc_bwd_k(const T* __restrict__
     }
   nh_col_commit<1, VN>(acc, ws, C, lpr, rpi, c0);
 }
-__global__ void __launch_bounds__(256) nh_d2f_k(const double* __restrict__ a, float* __restrict__ b, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) b[i] = (float)a[i];
-}
 extern "C" int ge_bias_act_nhwc_fwd(void* x, const float* bias, long rows, int C, float slope, int dtype, void* stream) {
   if (!x || !bias || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
   int lpr, rpi;
@@ -363,9 +364,7 @@ extern "C" int ge_bias_act_nhwc_bwd(const void* dy, const void* y, void* dx, flo
     return GE_ERR_UNSUPPORTED;
   }
   GE_LAUNCH_CHECK();
-  nh_reduce_launch(workspace, C, 1, nb, s);
-  GE_LAUNCH_CHECK();
-  nh_d2f_k<<<(C + 255) / 256, 256, 0, s>>>(ws, dbias, C);
+  nh_reduce_launch_f32(workspace, C, nb, dbias, 0, s);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
@@ -703,11 +702,6 @@ __global__ void __launch_bounds__(256) colsum_k(const T* __restrict__ x, float* 
     }
   nh_col_commit<1, VN>(acc, ws, C, lpr, rpi, c0);
 }
-__global__ void __launch_bounds__(256) colsum_finalize_k(const double* __restrict__ ws, float* __restrict__ out, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  out[c] = accumulate ? out[c] + (float)ws[c] : (float)ws[c];
-}
 template <typename T>
 static int colsum_launch(const void* x, long R, int C, float* out, void* ws, int accumulate, hipStream_t s) {
   constexpr int VN = V8<T>::N;
@@ -721,9 +715,7 @@ static int colsum_launch(const void* x, long R, int C, float* out, void* ws, int
   if (!gx) gx = 1;
   colsum_k<T><<<dim3(gx, chunks), 256, 0, s>>>((const T*)x, nh_partials(ws, C, 1), C, R, lpr, rpi);      // R == 0: zero partials
   GE_LAUNCH_CHECK();
-  nh_reduce_launch(ws, C, 1, gx, s);
-  GE_LAUNCH_CHECK();
-  colsum_finalize_k<<<(C + 255) / 256, 256, 0, s>>>((const double*)ws, out, C, accumulate);
+  nh_reduce_launch_f32(ws, C, gx, out, accumulate, s);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -229,20 +229,31 @@ __global__ void __launch_bounds__(64) window_attn_bwd_valu_k(const T* __restrict
   wsp[NBIAS + lane] = sm.dpad[lane];
 }
 
-// second stage of the deterministic reduction: sum the per-workgroup partials of each head
+// second stage of the deterministic reduction: sum the per-workgroup partials of each head.  grid (head, 32-entry group); 8 slices of
+// the workgroup range per entry, combined through LDS in a fixed order (one workgroup per head with a serial loop over up to 512
+// partials took 50-120 us per call)
 __global__ void __launch_bounds__(256) window_attn_bwd_reduce_k(const float* __restrict__ workspace, float* __restrict__ d_bias_table,
                                                                 float* __restrict__ d_qkv_bias, int nH, int C, int wg_per_head) {
-  const int head = blockIdx.x;
-  for (int i = threadIdx.x; i < WS_PER_WG; i += blockDim.x) {
-    float s = 0.f;
-    for (int w = 0; w < wg_per_head; ++w) s += workspace[((long)w * nH + head) * WS_PER_WG + i];
+  __shared__ float part[8][32];
+  const int head = blockIdx.x, j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int i = blockIdx.y * 32 + j;
+  float s = 0.f;
+  if (i < WS_PER_WG) {
+#pragma unroll 4
+    for (int w = sl; w < wg_per_head; w += 8) s += workspace[((long)w * nH + head) * WS_PER_WG + i];
+  }
+  part[sl][j] = s;
+  __syncthreads();
+  if (sl == 0 && i < WS_PER_WG) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += part[q][j];
     if (i < NBIAS) d_bias_table[i * nH + head] = s;
     else {
-      const int j = i - NBIAS;                 // 0..31 -> k part, 32..63 -> v part
-      d_qkv_bias[(j < HD ? C : 2 * C) + head * HD + (j & (HD - 1))] = s;
+      const int k = i - NBIAS;                 // 0..31 -> k part, 32..63 -> v part
+      d_qkv_bias[(k < HD ? C : 2 * C) + head * HD + (k & (HD - 1))] = s;
     }
   }
-  if (threadIdx.x < HD) d_qkv_bias[head * HD + threadIdx.x] = 0.f;   // pad queries receive no gradient
+  if (blockIdx.y == 0 && threadIdx.x < HD) d_qkv_bias[head * HD + threadIdx.x] = 0.f;   // pad queries receive no gradient
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
@@ -331,7 +342,7 @@ extern "C" int ge_window_attn_bwd(const void* qkv, const float* qkv_bias, const 
   } else {
     return GE_ERR_BAD_ARG;
   }
-  window_attn_bwd_reduce_k<<<(unsigned)nH, 256, 0, s>>>((const float*)workspace, d_bias_table, d_qkv_bias, nH, g.C, wph);
+  window_attn_bwd_reduce_k<<<dim3((unsigned)nH, (WS_PER_WG + 31) / 32), 256, 0, s>>>((const float*)workspace, d_bias_table, d_qkv_bias, nH, g.C, wph);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -1,0 +1,52 @@
+"""Which Python call sites launch the remaining ATen kernels of the bench step?  torch.profiler with stacks, grouped by the
+innermost repo frame; run on the GPU box: python scratch/aten_sites.py"""
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    sys.argv = ['bench.py', '--no-cpu-baseline', '--no-fp32', '--no-kernel-timing']
+    args = bench.parse()
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.tuning import use_miopen_find_db, use_tuned_gemms
+    use_miopen_find_db()
+    use_tuned_gemms('load')
+    torch.backends.cudnn.benchmark = True
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', args.config))
+    dev = torch.device('cuda', 0)
+    step, per_gpu, opt = bench.build_job(args, cfg, dev, 0, 'bf16')
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    want = ('aten::add', 'aten::add_', 'aten::copy_', 'aten::cat', 'aten::fill_', 'aten::zero_', 'aten::gelu', 'aten::gelu_backward',
+            'aten::sum', 'aten::mul', 'aten::div', 'aten::to', 'aten::_to_copy', 'aten::contiguous', 'aten::clone')
+    agg = defaultdict(lambda: [0.0, 0])
+    for ev in prof.events():
+        if ev.name not in want or ev.device_time_total <= 0:
+            continue
+        site = 'autograd/none'
+        for fr in ev.stack or []:
+            if '/gedepth_amd/' in fr or 'bench.py' in fr:
+                site = fr.split('/gedepth_amd/')[-1] if '/gedepth_amd/' in fr else fr
+                break
+        shp = str(ev.input_shapes)[:60] if ev.input_shapes else ''
+        key = (ev.name, site, shp)
+        agg[key][0] += ev.self_device_time_total
+        agg[key][1] += 1
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]
+    for (name, site, shp), (us, n) in rows:
+        print(f'{us / 1e3:7.3f} ms {n:4d}x {name:22s} {site[:70]:70s} {shp}')
+
+
+if __name__ == '__main__':
+    main()
