@@ -72,17 +72,25 @@ class FlatDDP(nn.Module):
     def _reset(self):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._works, self._next = [], 0
+        self._streams = [set() for _ in self.buckets]       # HIP streams on which a bucket's gradients were accumulated
 
     def _make_hook(self, idx):
         def hook(param):
             b = self.bucket_of[idx]
             self._pending[b] -= 1
+            if param.is_cuda:                                 # branches of the model may run (forward and backward) on side streams
+                self._streams[b].add(torch.cuda.current_stream(param.device))
             if self.overlap:
                 self._launch_ready()
         return hook
 
     def _launch(self, b):
         lo, hi, members = self.buckets[b]
+        if self.arena.flat_grad.is_cuda:                      # the launching stream first sees every stream that produced a member
+            cur = torch.cuda.current_stream(self.arena.flat_grad.device)
+            for st in self._streams[b]:
+                if st != cur:
+                    cur.wait_stream(st)
         if hasattr(self.arena, 'collect'):
             self.arena.collect(members)                       # gradients autograd handed over -> this bucket's arena slice
         buf = self.arena.flat_grad[lo:hi]
