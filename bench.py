@@ -240,17 +240,11 @@ def main():
     # ---- pass 2: the same steps again with HIP events around every hand-written kernel (roofline object)
     prof, stages = [], []
     if not args.no_kernel_timing and args.profile_steps > 0:
-        overlap = os.environ.get('GE_HAHI_OVERLAP')
-        os.environ['GE_HAHI_OVERLAP'] = '0'                   # per-kernel durations are taken with the kernels running alone
         kernels.PROFILER.enable()
         for _ in range(args.profile_steps):
             step()
         fence()
         kernels.PROFILER.disable()
-        if overlap is None:
-            del os.environ['GE_HAHI_OVERLAP']
-        else:
-            os.environ['GE_HAHI_OVERLAP'] = overlap
         prof = kernels.PROFILER.summary()
         stages = kernels.PROFILER.msda_bwd_stages()
     prof_ms_per_step = sum(r['total_ms'] for r in prof) / max(1, args.profile_steps)
@@ -265,8 +259,7 @@ def main():
             'config': {'workload': f'{args.config[:-3]}: DepthFormer-Swin{"T" if cfg.model.backbone.embed_dims == 96 else "L"} + '
                                    f'GEDepth-{"Adaptive" if "dynamic_pe_neck" in cfg.model else "Vanilla"}, '
                                    f'{args.height}x{args.width}, {per_gpu} img/GPU, full train step',
-                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'layout': args.layout,
-                       'streams': 1 if os.environ.get('GE_HAHI_OVERLAP', '1') == '0' else 2, 'window_attention': 'fp8-e4m3 mfma fwd' if args.attn == 'fp8' else 'bf16 mfma', 'last_loss': round(float(loss), 5),
+                       'global_batch': per_gpu * world, 'parallelism': f'dp{world}', 'allreduce_dtype': args.allreduce_dtype, 'layout': args.layout, 'window_attention': 'fp8-e4m3 mfma fwd' if args.attn == 'fp8' else 'bf16 mfma', 'last_loss': round(float(loss), 5),
                        'params': int(optimizer.arena.numel)},
         }
         res['eager_fallbacks'] = dict(kernels.FALLBACKS)      # modules that took ATen where a HIP kernel exists: must be empty
@@ -281,7 +274,7 @@ def main():
                                'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
                                'avg_us': round(dom['avg_us'], 2), 'launches': dom['launches'],
                                'algorithmic_bytes_per_launch': int(dom['bytes_per_launch']),
-                               'timed': f'HIP events on the launch stream, separate pass of {args.profile_steps} steps after the timed region, single stream'}
+                               'timed': f'HIP events on the launch stream, separate pass of {args.profile_steps} steps after the timed region'}
             res['roofline']['traffic'] = pmc_traffic(dom['name'])
             step_ms = 1e3 * elapsed / args.steps
             res['kernels'] = [{'name': r['name'], 'launches': r['launches'], 'avg_us': round(r['avg_us'], 2),

@@ -194,40 +194,13 @@ class HAHIHeteroNeck(BaseModule):
                 w, b = self.reference_points.weight, self.reference_points.bias
                 ref = torch.stack((torch.mv(pm.t(), w[0]), torch.mv(pm.t(), w[1])), -1).add(b).sigmoid()[None]
             ref = ref[:, :, None, :].expand(bs, -1, len(shapes), 2)
-            side = self._side_stream(dev)
-            if side is None:
-                fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv)
-            else:
-                # The cross-attention (VALU-bound gathers, 5 ms forward / 17 ms backward at the KITTI shape) and the per-level
-                # fusion convolutions below (MFMA-bound) only share `src`: the attention runs on a second HIP stream, and so
-                # does its backward (autograd replays a node on the stream of its forward), concurrently with the convolutions.
-                main = torch.cuda.current_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv)
-                for t in (conv_skip, pos_map, src, feat_conv, ref):
-                    t.record_stream(side)                     # allocated on the main stream, read on the side stream
+            fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv)
         else:
-            side = None
             fused = torch.cat([conv_skip, feat_conv], dim=1)
         # one split (backward: ONE concatenating write of the level gradients) instead of per-level slices, whose backward
         # zero-fills a full (B, sum HW, C) tensor per level and adds the three of them
-        outs = [None]
+        outs = [self.conv_fusion(fused)]
         for i, (ft, piece) in enumerate(zip(feats_trans, torch.split(src, [h * w for h, w in shapes], dim=1))):
             outs.append(self.trans_fusion[i](concat_tokens_map(piece, ft, tokens_first=False)))
-        if side is not None:
-            torch.cuda.current_stream(dev).wait_stream(side)
-            fused.record_stream(torch.cuda.current_stream(dev))
-        outs[0] = self.conv_fusion(fused)
         return tuple(outs)
 
-    def _side_stream(self, dev):
-        """Second HIP stream for the cross-attention branch (training on the GPU only; ``GE_HAHI_OVERLAP=0`` or
-        ``neck.overlap_streams = False`` keep everything on one stream, e.g. for per-kernel timing)."""
-        import os
-        if (dev.type != 'cuda' or not self.training or not torch.is_grad_enabled() or not getattr(self, 'overlap_streams', True)
-                or os.environ.get('GE_HAHI_OVERLAP', '1') == '0'):
-            return None
-        if getattr(self, '_side', None) is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-        return self._side
