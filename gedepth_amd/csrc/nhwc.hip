@@ -122,26 +122,37 @@ __global__ void __launch_bounds__(256) bn_apply_nhwc_k(const T* __restrict__ x, 
     float v[VN];
     V8<T>::ld(x + r * C + c0, v);
 #pragma unroll
-    for (int k = 0; k < VN; ++k) { const float tv = v[k] * a[k] + b[k]; v[k] = tv > 0.f ? tv : tv * slope; }
+    for (int k = 0; k < VN; ++k) { const float tv = __fmaf_rn(v[k], a[k], b[k]); v[k] = tv > 0.f ? tv : tv * slope; }
     V8<T>::st(y + r * C + c0, v);
   }
 }
-template <typename T>
+// RECOMP: the activation decision y > 0 is recomputed from x with the forward's coefficients (same fma, same operands) instead of
+// reading y: one tensor less per pass (2 of the 7 passes of the backward)
+template <typename T, bool RECOMP>
 __global__ void __launch_bounds__(256) bn_bwd_stats_nhwc_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
                                                            float* __restrict__ ws, int C, long R, int lpr, int rpi, float slope) {
   constexpr int VN = V8<T>::N;
   const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
   const int c0 = lane * VN;
-  float mu[VN], rsd[VN], acc[2][VN];
+  float mu[VN], rsd[VN], acc[2][VN], fa[VN], fb[VN];
 #pragma unroll
-  for (int v = 0; v < VN; ++v) { mu[v] = save_mean[c0 + v]; rsd[v] = save_rstd[c0 + v]; acc[0][v] = 0.f; acc[1][v] = 0.f; }
+  for (int v = 0; v < VN; ++v) {
+    mu[v] = save_mean[c0 + v]; rsd[v] = save_rstd[c0 + v]; acc[0][v] = 0.f; acc[1][v] = 0.f;
+    if (RECOMP) { fa[v] = gamma[c0 + v] * rsd[v]; fb[v] = __fmaf_rn(-mu[v], fa[v], beta[c0 + v]); }
+  }
   if (rs < rpi)
     for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
       float g[VN], yv[VN], xv[VN];
       V8<T>::ld(dy + r * C + c0, g);
-      V8<T>::ld(y + r * C + c0, yv);
       V8<T>::ld(x + r * C + c0, xv);
+      if (RECOMP) {
+#pragma unroll
+        for (int k = 0; k < VN; ++k) yv[k] = __fmaf_rn(xv[k], fa[k], fb[k]);
+      } else {
+        V8<T>::ld(y + r * C + c0, yv);
+      }
 #pragma unroll
       for (int k = 0; k < VN; ++k) {
         const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
@@ -151,25 +162,31 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_nhwc_k(const T* __restrict__
     }
   nh_col_commit<2, VN>(acc, ws, C, lpr, rpi, c0);
 }
-template <typename T>
+template <typename T, bool RECOMP>
 __global__ void __launch_bounds__(256) bn_bwd_apply_nhwc_k(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
-                                                           const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-                                                           const float* __restrict__ coef, T* __restrict__ dx, int C, long R, int lpr, int rpi,
-                                                           float slope) {
+                                                           const float* __restrict__ beta, const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, const float* __restrict__ coef,
+                                                           T* __restrict__ dx, int C, long R, int lpr, int rpi, float slope) {
   constexpr int VN = V8<T>::N;
   const int t = threadIdx.x, lane = t % lpr, rs = t / lpr;
   if (rs >= rpi) return;
   const int c0 = lane * VN;
-  float a[VN], m1[VN], m2[VN], mu[VN], rsd[VN];
+  float a[VN], m1[VN], m2[VN], mu[VN], rsd[VN], fb[VN];
 #pragma unroll
   for (int k = 0; k < VN; ++k) {
     a[k] = coef[c0 + k]; m1[k] = coef[C + c0 + k]; m2[k] = coef[2 * C + c0 + k]; mu[k] = save_mean[c0 + k]; rsd[k] = save_rstd[c0 + k];
+    if (RECOMP) fb[k] = __fmaf_rn(-mu[k], a[k], beta[c0 + k]);          // coef[c] is gamma * rstd, the forward's scale
   }
   for (long r = (long)blockIdx.x * rpi + rs; r < R; r += (long)gridDim.x * rpi) {
     float g[VN], yv[VN], xv[VN];
     V8<T>::ld(dy + r * C + c0, g);
-    V8<T>::ld(y + r * C + c0, yv);
     V8<T>::ld(x + r * C + c0, xv);
+    if (RECOMP) {
+#pragma unroll
+      for (int k = 0; k < VN; ++k) yv[k] = __fmaf_rn(xv[k], a[k], fb[k]);
+    } else {
+      V8<T>::ld(y + r * C + c0, yv);
+    }
 #pragma unroll
     for (int k = 0; k < VN; ++k) {
       const float gg = yv[k] > 0.f ? g[k] : g[k] * slope;
@@ -197,7 +214,7 @@ __global__ void __launch_bounds__(256) bn_finalize_nhwc_k(const double* __restri
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
   const float a = gamma[c] * rstd;
   coef[c] = a;
-  coef[C + c] = beta[c] - (float)mean * a;
+  coef[C + c] = __fmaf_rn(-(float)mean, a, beta[c]);       // explicit fma: bn_bwd_*_nhwc_k<.., true> recompute exactly this
 }
 __global__ void __launch_bounds__(256) bn_bwd_finalize_nhwc_k(const double* __restrict__ ws, const float* __restrict__ gamma,
                                                               const float* __restrict__ save_rstd, float* __restrict__ dgamma,
@@ -251,7 +268,7 @@ static int bn_nhwc_fwd_launch(const void* x, const float* gamma, const float* be
   return GE_OK;
 }
 template <typename T>
-static int bn_nhwc_bwd_launch(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
+static int bn_nhwc_bwd_launch(const void* dy, const void* y, const void* x, const float* gamma, const float* beta, const float* save_mean,
                               const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, long R, int C, float slope,
                               hipStream_t s) {
   int lpr, rpi;
@@ -259,14 +276,16 @@ static int bn_nhwc_bwd_launch(const void* dy, const void* y, const void* x, cons
   double* ws = (double*)workspace;
   float* coef = (float*)(ws + 2 * C);
   const unsigned nb = nh_grid_rows(R, rpi);
-  bn_bwd_stats_nhwc_k<T><<<nb, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, nh_partials(workspace, C, 2), C, R, lpr,
-                                            rpi, slope);
+  float* part = nh_partials(workspace, C, 2);
+  if (beta) bn_bwd_stats_nhwc_k<T, true><<<nb, 256, 0, s>>>((const T*)dy, nullptr, (const T*)x, gamma, beta, save_mean, save_rstd, part, C, R, lpr, rpi, slope);
+  else bn_bwd_stats_nhwc_k<T, false><<<nb, 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, gamma, beta, save_mean, save_rstd, part, C, R, lpr, rpi, slope);
   GE_LAUNCH_CHECK();
   nh_reduce_launch(workspace, C, 2, nb, s);
   GE_LAUNCH_CHECK();
   bn_bwd_finalize_nhwc_k<<<(C + 255) / 256, 256, 0, s>>>(ws, gamma, save_rstd, dgamma, dbeta, coef, C, (double)R);
   GE_LAUNCH_CHECK();
-  bn_bwd_apply_nhwc_k<T><<<nh_grid_apply(R, rpi), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, save_mean, save_rstd, coef, (T*)dx, C, R, lpr, rpi, slope);
+  if (beta) bn_bwd_apply_nhwc_k<T, true><<<nh_grid_apply(R, rpi), 256, 0, s>>>((const T*)dy, nullptr, (const T*)x, beta, save_mean, save_rstd, coef, (T*)dx, C, R, lpr, rpi, slope);
+  else bn_bwd_apply_nhwc_k<T, false><<<nh_grid_apply(R, rpi), 256, 0, s>>>((const T*)dy, (const T*)y, (const T*)x, beta, save_mean, save_rstd, coef, (T*)dx, C, R, lpr, rpi, slope);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
@@ -278,12 +297,13 @@ extern "C" int ge_bn_act_nhwc_fwd(const void* x, const float* gamma, const float
   if (dtype == GE_BF16) return bn_nhwc_fwd_launch<bf16_t>(x, gamma, beta, y, save_mean, save_rstd, running_mean, running_var, workspace, rows, C, eps, momentum, slope, ge_stream(stream));
   return GE_ERR_UNSUPPORTED;
 }
-extern "C" int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                                  const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, long rows, int C,
-                                  float slope, int dtype, void* stream) {
-  if (!dy || !y || !x || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
-  if (dtype == GE_F32) return bn_nhwc_bwd_launch<float>(dy, y, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, workspace, rows, C, slope, ge_stream(stream));
-  if (dtype == GE_BF16) return bn_nhwc_bwd_launch<bf16_t>(dy, y, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, workspace, rows, C, slope, ge_stream(stream));
+// exactly one of `y` (the forward output) and `beta` (the forward's shift: the activation decision is recomputed from x) is needed
+extern "C" int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
+                                  const float* save_mean, const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace,
+                                  long rows, int C, float slope, int dtype, void* stream) {
+  if (!dy || (!y && !beta) || !x || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || C <= 0) return GE_ERR_BAD_ARG;
+  if (dtype == GE_F32) return bn_nhwc_bwd_launch<float>(dy, y, x, gamma, beta, save_mean, save_rstd, dx, dgamma, dbeta, workspace, rows, C, slope, ge_stream(stream));
+  if (dtype == GE_BF16) return bn_nhwc_bwd_launch<bf16_t>(dy, y, x, gamma, beta, save_mean, save_rstd, dx, dgamma, dbeta, workspace, rows, C, slope, ge_stream(stream));
   return GE_ERR_UNSUPPORTED;
 }
 

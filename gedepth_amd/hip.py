@@ -55,7 +55,7 @@ SIGNATURES = {
     'ge_slope_class_ddad': (_i, [_vp, _vp, _d, _vp, _i, _i, _vp]),
     'ge_pe_channels': (_i, [_vp, _vp, _f, _l, _vp]),
     'ge_bn_act_nhwc_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _f, _f, _i, _vp]),
-    'ge_bn_act_nhwc_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
+    'ge_bn_act_nhwc_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     'ge_bias_act_nhwc_fwd': (_i, [_vp, _vp, _l, _i, _f, _i, _vp]),
     'ge_bias_act_nhwc_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     'ge_bilinear_nhwc_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -637,7 +637,7 @@ class _BNAct(torch.autograd.Function):
                 hip.lib().ge_bn_act_nhwc_fwd(_raw_ptr(x, 'x'), hip.ptr(w), hip.ptr(b), _raw_ptr(y, 'y'), hip.ptr(stats[0]), hip.ptr(stats[1]),
                                              hip.ptr(running_mean, _f32), hip.ptr(running_var, _f32), hip.ptr(ws), N * H * W, C, eps,
                                              momentum, slope, hip.dtype_code(x), hip.stream()), 'ge_bn_act_nhwc_fwd'))
-            ctx.save_for_backward(x, y, w, stats)
+            ctx.save_for_backward(x, b, w, stats)            # not y: the backward recomputes the activation decision from x
             ctx.slope = slope
             return y
         PROFILER.run(f'bn_act_fwd[{N}x{C}x{H}x{W} {_tag(x)}]', 3 * x.numel() * _es(x), lambda: hip.check(
@@ -650,15 +650,15 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, w, stats = ctx.saved_tensors
+        x, y, w, stats = ctx.saved_tensors                   # channels-last: the second entry is beta, not y
         N, C, H, W = x.shape
         dx = torch.empty_like(x)
         dwb = torch.empty(2, C, device=x.device, dtype=_f32)
         ws = torch.empty(int(hip.lib().ge_nhwc_workspace(C, 2) if ctx.cl else hip.lib().ge_bn_workspace(C)), device=x.device, dtype=torch.uint8)
         if ctx.cl:
             dy = _cl(dy.to(x.dtype))
-            PROFILER.run(f'bn_act_nhwc_bwd[{N}x{C}x{H}x{W} {_tag(x)}]', 7 * x.numel() * _es(x), lambda: hip.check(
-                hip.lib().ge_bn_act_nhwc_bwd(_raw_ptr(dy, 'dy'), _raw_ptr(y, 'y'), _raw_ptr(x, 'x'), hip.ptr(w), hip.ptr(stats[0]), hip.ptr(stats[1]),
+            PROFILER.run(f'bn_act_nhwc_bwd[{N}x{C}x{H}x{W} {_tag(x)}]', 5 * x.numel() * _es(x), lambda: hip.check(
+                hip.lib().ge_bn_act_nhwc_bwd(_raw_ptr(dy, 'dy'), None, _raw_ptr(x, 'x'), hip.ptr(w), hip.ptr(y, _f32), hip.ptr(stats[0]), hip.ptr(stats[1]),
                                              _raw_ptr(dx, 'dx'), hip.ptr(dwb[0]), hip.ptr(dwb[1]), hip.ptr(ws), N * H * W, C, ctx.slope,
                                              hip.dtype_code(x), hip.stream()), 'ge_bn_act_nhwc_bwd'))
             return dx, dwb[0], dwb[1], None, None, None, None, None

@@ -273,7 +273,8 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
  * NCHW <-> NHWC batched_transpose kernels, and tokens <-> maps become views.  C must be a multiple of the 16-byte vector
  * (8 bf16 / 4 f32) and at most 256 such vectors wide, pointers 16-byte aligned; otherwise GE_ERR_UNSUPPORTED (the caller keeps NCHW).
  * ge_bn_act_nhwc_*: as ge_bn_act_* with a workspace of ge_nhwc_workspace(C, 2) bytes; statistics are column sums (fp32 partial per
- *   workgroup, fp64 across workgroups, no atomics).
+ *   workgroup, fp64 across workgroups, no atomics).  The backward takes either `y` (forward output) or `beta` (then y may be
+ *   NULL and the activation decision y > 0 is recomputed from x with the forward's fma — one tensor less per pass).
  * ge_bias_act_nhwc_*: as ge_bias_act_*; the backward needs a workspace of ge_nhwc_workspace(C, 1) bytes, d_bias is fully written.
  * ge_bilinear_nhwc_*: as ge_bilinear_* on (N, H, W, C); the backward takes an optional workspace of N*Ho*Wi*C floats that
  *   enables the separable two-pass form for up-sampling factors > 3 (PE necks: 11x35 -> 176x560).
@@ -288,9 +289,9 @@ int ge_pe_channels(const float* raw, float* norm, float depth_scale, long n, voi
 int ge_bn_act_nhwc_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
                        float* running_mean, float* running_var, void* workspace, long rows, int C, float eps,
                        float momentum, float slope, int dtype, void* stream);
-int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* save_mean,
-                       const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace, long rows, int C,
-                       float slope, int dtype, void* stream);
+int ge_bn_act_nhwc_bwd(const void* dy, const void* y, const void* x, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_rstd, void* dx, float* dgamma, float* dbeta, void* workspace,
+                       long rows, int C, float slope, int dtype, void* stream);
 int ge_bias_act_nhwc_fwd(void* x, const float* bias, long rows, int C, float slope, int dtype, void* stream);
 int ge_bias_act_nhwc_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, long rows, int C,
                          float slope, int dtype, void* stream);

@@ -28,6 +28,17 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         step()
         torch.cuda.synchronize()
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 5
+    from torch.autograd import DeviceType
+    busy = sum(ev.device_time_total for ev in prof.events() if ev.device_type == DeviceType.CUDA)
+    print(f'GPU kernel time in the profiled step: {busy / 1e3:.2f} ms; un-profiled step wall time: {wall * 1e3:.2f} ms; '
+          f'kernels: {sum(1 for ev in prof.events() if ev.device_type == DeviceType.CUDA)}')
     want = ('aten::add', 'aten::add_', 'aten::copy_', 'aten::cat', 'aten::fill_', 'aten::zero_', 'aten::gelu', 'aten::gelu_backward',
             'aten::sum', 'aten::mul', 'aten::div', 'aten::to', 'aten::_to_copy', 'aten::contiguous', 'aten::clone')
     agg = defaultdict(lambda: [0.0, 0])
