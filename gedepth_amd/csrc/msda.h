@@ -72,12 +72,18 @@ template <> struct RowDot<bf16_t> {
 };
 
 
+// Row indices and pitches are formed with the 24-bit integer multiply (v_mul_i32_i24 / v_mad_i32_i24: full rate on CDNA, where the
+// 32-bit v_mul_lo_u32 takes four passes — six of those per sampling point were ~15 % of the d_loc / d_attw kernel).  Operands are
+// map coordinates, widths and row pitches; msda_levels() refuses maps of 2^23 positions or more.
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
 static inline int msda_levels(const int* spatial_hw, int L, int Nv, MsdaLevels& lv) {
   if (L < 1 || L > MSDA_MAX_L) return GE_ERR_UNSUPPORTED;
   long start = 0;
   for (int l = 0; l < L; ++l) {
     lv.H[l] = spatial_hw[2 * l]; lv.W[l] = spatial_hw[2 * l + 1]; lv.start[l] = (int)start;
     if (lv.H[l] <= 0 || lv.W[l] <= 0) return GE_ERR_BAD_ARG;
+    if ((long)lv.H[l] * lv.W[l] >= (1L << 23)) return GE_ERR_UNSUPPORTED;          // mul24 index arithmetic
     start += (long)lv.H[l] * lv.W[l];
   }
   return start == Nv ? GE_OK : GE_ERR_BAD_ARG;

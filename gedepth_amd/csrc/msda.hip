@@ -93,10 +93,10 @@ __global__ void __launch_bounds__(256) msda_fwd_k(const T* __restrict__ value, M
         const float wxa = x0 >= 0 ? 1.f - ax : 0.f, wxb = x0 + 1 < Wl ? ax : 0.f;
         const float wya = y0 >= 0 ? 1.f - ay : 0.f, wyb = y0 + 1 < Hl ? ay : 0.f;
         float v00[CPL], v01[CPL], v10[CPL], v11[CPL];
-        VecL<T>::ld(vl + (ya * Wl + xa) * nh64, v00);
-        VecL<T>::ld(vl + (ya * Wl + xb) * nh64, v01);
-        VecL<T>::ld(vl + (yb * Wl + xa) * nh64, v10);
-        VecL<T>::ld(vl + (yb * Wl + xb) * nh64, v11);
+        VecL<T>::ld(vl + mul24(mul24(ya, Wl) + xa, nh64), v00);
+        VecL<T>::ld(vl + mul24(mul24(ya, Wl) + xb, nh64), v01);
+        VecL<T>::ld(vl + mul24(mul24(yb, Wl) + xa, nh64), v10);
+        VecL<T>::ld(vl + mul24(mul24(yb, Wl) + xb, nh64), v11);
         const float w00 = wya * wxa * wgt, w01 = wya * wxb * wgt, w10 = wyb * wxa * wgt, w11 = wyb * wxb * wgt;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) acc[i] += w00 * v00[i] + w01 * v01[i] + w10 * v10[i] + w11 * v11[i];
@@ -277,10 +277,10 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value
       const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);                           \
       const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);                           \
       const bool k_xa = in && x0 >= 0, k_xb = in && x0 + 1 < Wl, k_ya = y0 >= 0, k_yb = y0 + 1 < Hl;      \
-      const lw_raw_t r00 = *(const lw_raw_t*)(vl + (ya * Wl + xa) * nh64);                        \
-      const lw_raw_t r01 = *(const lw_raw_t*)(vl + (ya * Wl + xb) * nh64);                        \
-      const lw_raw_t r10 = *(const lw_raw_t*)(vl + (yb * Wl + xa) * nh64);                        \
-      const lw_raw_t r11 = *(const lw_raw_t*)(vl + (yb * Wl + xb) * nh64);                        \
+      const lw_raw_t r00 = *(const lw_raw_t*)(vl + mul24(mul24(ya, Wl) + xa, nh64));                        \
+      const lw_raw_t r01 = *(const lw_raw_t*)(vl + mul24(mul24(ya, Wl) + xb, nh64));                        \
+      const lw_raw_t r10 = *(const lw_raw_t*)(vl + mul24(mul24(yb, Wl) + xa, nh64));                        \
+      const lw_raw_t r11 = *(const lw_raw_t*)(vl + mul24(mul24(yb, Wl) + xb, nh64));                        \
       float d00 = RowDot<T>::dot(go, r00), d01 = RowDot<T>::dot(go, r01);                                 \
       float d10 = RowDot<T>::dot(go, r10), d11 = RowDot<T>::dot(go, r11);                                 \
       d00 = (k_ya && k_xa) ? d00 : 0.f; d01 = (k_ya && k_xb) ? d01 : 0.f;   /* selects: a masked corner may hold anything */ \
@@ -410,13 +410,20 @@ __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins,
   const long g_first = hsplit == 1 ? g_lo : g_lo + ((hsel - g_lo % nH) + nH) % nH;
   const long g_step = hsplit == 1 ? 1 : nH;
   const long n_local = g_first < g_hi ? ((g_hi - g_first + g_step - 1) / g_step) * LP : 0;
-  for (long j = threadIdx.x; j < n_local; j += 256) {
-    const long grp_l = g_first + (j / LP) * g_step;
+  // per-point index arithmetic in 32 bits with shifts when L*P, P and nH are powers of two (every GEDepth config): a 64-bit
+  // division by a run-time value is ~50 VALU instructions, and this loop has one thread per sampling point
+  const int sh_lp = (LP & (LP - 1)) ? -1 : __ffs(LP) - 1, sh_p = (P & (P - 1)) ? -1 : __ffs(P) - 1, sh_h = (nH & (nH - 1)) ? -1 : __ffs(nH) - 1;
+  const int n_loc32 = (int)n_local, gstep32 = (int)g_step;           // n_local <= MSDA_SEG
+  const long ib0 = g_first * LP;
+  const int gstep_lp = gstep32 * LP;
+  for (int j = threadIdx.x; j < n_loc32; j += 256) {
+    const int jg = sh_lp >= 0 ? (j >> sh_lp) : j / LP;
+    const int lp = j - mul24(jg, LP);
+    const long grp_l = g_first + mul24(jg, gstep32);
     const int grp_b = (int)grp_l;                        // q*nH + head
-    const int lp = (int)(j % LP);
-    const long ib = grp_l * LP + lp;
-    const int l = lp / P;
-    const int q = grp_b / nH, head = grp_b - q * nH;
+    const long ib = ib0 + mul24(jg, gstep_lp) + lp;
+    const int l = sh_p >= 0 ? (lp >> sh_p) : lp / P;
+    const int q = sh_h >= 0 ? (grp_b >> sh_h) : grp_b / nH, head = grp_b - mul24(q, nH);
     const int Hl = lv.H[l], Wl = lv.W[l];
     const long pt = (long)b * npts_b + ib;
     const float2 xy = ((const float2*)loc)[pt];
@@ -427,7 +434,7 @@ __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins,
     const float ax = x - xf, ay = y - yf;
     const float wgt = FILL ? attw[pt] : 0.f;
     const int ntx = bins.ntx[l];
-    const int lb0 = head * ntiles + bins.first_tile[l] - wg0;
+    const int lb0 = mul24(head, ntiles) + bins.first_tile[l] - wg0;
     // tile columns / rows that hold an in-image corner: the left column x0 (if >= 0) and the right column x0+1 (if < W)
     const bool xa = x0 >= 0, xb = x0 + 1 < Wl, ya = y0 >= 0, yb = y0 + 1 < Hl;
     const int txa = x0 >> 3, txb = (x0 + 1) >> 3, tya = y0 >> 2, tyb = (y0 + 1) >> 2;
@@ -436,7 +443,7 @@ __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins,
     for (int jy = 0; jy <= two_y; ++jy)
       for (int jx = 0; jx <= two_x; ++jx) {
         const int tx = jx ? txb : tx_first, ty = jy ? tyb : ty_first;
-        const int slot = atomicAdd(&hist[lb0 + ty * ntx + tx], 1);        // LDS
+        const int slot = atomicAdd(&hist[lb0 + mul24(ty, ntx) + tx], 1);        // LDS
         if (FILL) {
           const int lx1 = x0 - tx * MSDA_TW + 1, ly1 = y0 - ty * MSDA_TH + 1;   // top-left corner relative to the tile, +1: [0,8] x [0,4]
           ws.entries[slot] = make_int4((q << 7) | (ly1 << 4) | lx1, __float_as_int(wgt), __float_as_int(ax), __float_as_int(ay));

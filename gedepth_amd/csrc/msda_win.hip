@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
         const float bx = 1.f - t.ax, by = 1.f - t.ay;
         const float wxa = (in && t.kxa) ? bx : 0.f, wxb = (in && t.kxb) ? t.ax : 0.f;
         const float wya = t.kya ? by : 0.f, wyb = t.kyb ? t.ay : 0.f;
-        const int i00 = staged ? (t.ya - y0w) * bw + (t.xa - x0w) : t.ya * Wl + t.xa;
+        const int i00 = staged ? mul24(t.ya - y0w, bw) + (t.xa - x0w) : mul24(t.ya, Wl) + t.xa;
         pk[i] = in ? (i00 | ((t.xb - t.xa) << 30) | ((t.yb - t.ya) << 31)) : 0;
         w00[i] = wya * wxa * pw[i]; w01[i] = wya * wxb * pw[i]; w10[i] = wyb * wxa * pw[i]; w11[i] = wyb * wxb * pw[i];
       }
@@ -244,8 +244,8 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
             r00 = win[i00 * G + sub]; r01 = win[(i00 + dx) * G + sub];
             r10 = win[i10 * G + sub]; r11 = win[(i10 + dx) * G + sub];
           } else {
-            r00 = gsrc[(long)i00 * s16]; r01 = gsrc[(long)(i00 + dx) * s16];
-            r10 = gsrc[(long)i10 * s16]; r11 = gsrc[(long)(i10 + dx) * s16];
+            r00 = gsrc[mul24(i00, s16)]; r01 = gsrc[mul24(i00 + dx, s16)];
+            r10 = gsrc[mul24(i10, s16)]; r11 = gsrc[mul24(i10 + dx, s16)];
           }
           MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, a, b, c, d);
         }
@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
             r00 = win[(ra + xa) * G + sub]; r01 = win[(ra + xb) * G + sub];
             r10 = win[(rb + xa) * G + sub]; r11 = win[(rb + xb) * G + sub];
           } else {
-            r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
-            r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
+            r00 = gsrc[mul24(mul24(t.ya, Wl) + t.xa, s16)]; r01 = gsrc[mul24(mul24(t.ya, Wl) + t.xb, s16)];
+            r10 = gsrc[mul24(mul24(t.yb, Wl) + t.xa, s16)]; r11 = gsrc[mul24(mul24(t.yb, Wl) + t.xb, s16)];
           }
           MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, wya * wxa * wgt, wya * wxb * wgt, wyb * wxa * wgt, wyb * wxb * wgt);
         }
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ v
       for (int i = 0; i < MW_QPG; ++i) {
         const bool in = px[i] > -1.5f;
         const MwTap t = mw_tap(px[i], py[i], Wl, Hl);
-        const int i00 = staged ? (t.ya - y0w) * bw + (t.xa - x0w) : t.ya * Wl + t.xa;
+        const int i00 = staged ? mul24(t.ya - y0w, bw) + (t.xa - x0w) : mul24(t.ya, Wl) + t.xa;
         const int m = (t.kxa ? 1 : 0) | (t.kxb ? 2 : 0) | (t.kya ? 4 : 0) | (t.kyb ? 8 : 0);
         pk[i] = in ? (i00 | (m << 26) | ((t.xb - t.xa) << 30) | ((t.yb - t.ya) << 31)) : 0;
         px[i] = t.ax; py[i] = t.ay;
@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ v
             r00 = lwin[i00 * G + sub]; r01 = lwin[(i00 + dx) * G + sub];
             r10 = lwin[i10 * G + sub]; r11 = lwin[(i10 + dx) * G + sub];
           } else {
-            r00 = gsrc[(long)i00 * s16]; r01 = gsrc[(long)(i00 + dx) * s16];
-            r10 = gsrc[(long)i10 * s16]; r11 = gsrc[(long)(i10 + dx) * s16];
+            r00 = gsrc[mul24(i00, s16)]; r01 = gsrc[mul24(i00 + dx, s16)];
+            r10 = gsrc[mul24(i10, s16)]; r11 = gsrc[mul24(i10 + dx, s16)];
           }
           float d00 = RowDot<T>::dot(go[i], r00), d01 = RowDot<T>::dot(go[i], r01);
           float d10 = RowDot<T>::dot(go[i], r10), d11 = RowDot<T>::dot(go[i], r11);
@@ -370,8 +370,8 @@ __global__ void __launch_bounds__(256) msda_bwd_lw_win_k(const T* __restrict__ v
             r00 = lwin[(ra + xa) * G + sub]; r01 = lwin[(ra + xb) * G + sub];
             r10 = lwin[(rb + xa) * G + sub]; r11 = lwin[(rb + xb) * G + sub];
           } else {
-            r00 = gsrc[(long)(t.ya * Wl + t.xa) * s16]; r01 = gsrc[(long)(t.ya * Wl + t.xb) * s16];
-            r10 = gsrc[(long)(t.yb * Wl + t.xa) * s16]; r11 = gsrc[(long)(t.yb * Wl + t.xb) * s16];
+            r00 = gsrc[mul24(mul24(t.ya, Wl) + t.xa, s16)]; r01 = gsrc[mul24(mul24(t.ya, Wl) + t.xb, s16)];
+            r10 = gsrc[mul24(mul24(t.yb, Wl) + t.xa, s16)]; r11 = gsrc[mul24(mul24(t.yb, Wl) + t.xb, s16)];
           }
           float d00 = RowDot<T>::dot(go[i], r00), d01 = RowDot<T>::dot(go[i], r01);
           float d10 = RowDot<T>::dot(go[i], r10), d11 = RowDot<T>::dot(go[i], r11);
