@@ -63,10 +63,14 @@ template <> struct RowDot<float> {
 };
 template <> struct RowDot<bf16_t> {
   static __device__ __forceinline__ float dot(const lw_raw_t& a, const lw_raw_t& b) {
+    // element copies first: hipcc (ROCm 7.2) miscompiles __builtin_bit_cast(bf16x2_t, a[i]) on a vector-element lvalue — every i reads
+    // element 0 (one dword loaded, dotted four times; tests/test_kernels_gpu.py::test_msda_bf16_gradients_vs_oracle pins this)
+    const unsigned int a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
     float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]), __builtin_bit_cast(bf16x2_t, b[i]), s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a0), __builtin_bit_cast(bf16x2_t, b0), s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a1), __builtin_bit_cast(bf16x2_t, b1), s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a2), __builtin_bit_cast(bf16x2_t, b2), s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a3), __builtin_bit_cast(bf16x2_t, b3), s, false);
     return s;
   }
 };

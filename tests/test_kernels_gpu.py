@@ -391,6 +391,37 @@ def test_msda_bf16(dev):
     assert vg.grad.dtype == torch.bfloat16 and torch.isfinite(vg.grad.float()).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [13, 0, 8, 7])
+@pytest.mark.parametrize('binned', [True, False])
+def test_msda_bf16_gradients_vs_oracle(dev, mode, binned, monkeypatch):
+    """bf16 storage path against the fp32 CPU oracle evaluated on the SAME bf16-rounded value / gradient rows: d_loc and d_attw are
+    fp32 sums of bf16 products (exact up to summation order), d_value and out are rounded to bf16 once.  Covers the bf16-pair dot
+    products (v_dot2) of the d_loc / d_attw kernels in every kernel-selection mode."""
+    from gedepth_amd import kernels
+    from gedepth_amd.kernels import ms_deform_attn, msda_mode
+    monkeypatch.setattr(kernels, 'MSDA_BINNED_BACKWARD', binned)
+    shapes = ((40, 70), (20, 35), (10, 18), (5, 9))
+    qshapes = [(20, 35)]
+    value, loc, aw, go, shapes = _msda_inputs(5, B=2, Nq=20 * 35, shapes=shapes)
+    vb, gb = value.bfloat16(), go.bfloat16()
+    vc, lc, ac = vb.float().requires_grad_(True), loc.clone().requires_grad_(True), aw.clone().requires_grad_(True)
+    ref = O.msda_core(vc, shapes, lc, ac)
+    ref.backward(gb.float())
+    old = msda_mode(mode)
+    try:
+        vg = vb.to(dev).requires_grad_(True)
+        lg, ag = loc.to(dev).requires_grad_(True), aw.to(dev).requires_grad_(True)
+        out = ms_deform_attn(vg, shapes, lg, ag, query_shapes=qshapes)
+        out.backward(gb.to(dev))
+    finally:
+        msda_mode(old)
+    close_scaled(out.float(), ref, rel=1e-2, what='bf16 out')
+    close_scaled(vg.grad.float(), vc.grad, rel=1e-2, what='bf16 d value')
+    close_scaled(ag.grad, ac.grad, rel=2e-5, what='bf16 d attw')
+    close_scaled(lg.grad, lc.grad, rel=2e-4, what='bf16 d loc')
+
+
 def test_msda_module_golden(dev, golden):
     """Whole MultiScaleDeformableAttention module vs the fixture (mmcv 1.3.13 semantics, dropout off)."""
     from gedepth_amd.depth.models.necks.hahi import MultiScaleDeformableAttention
