@@ -624,9 +624,6 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
       int cls = 0;
       int run_end = __builtin_amdgcn_readfirstlane(s_start[1]);
       f32x2_t accT = {0.f, 0.f}, accB = {0.f, 0.f};        // top pair (ly: lx, lx+1), bottom pair (ly+1: lx, lx+1)
-      uint32_t gbits[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) gbits[k] = 0u;
       MSDA_GATHER(0)
       MSDA_PARK()
       for (int blk = 0; blk < nb; ++blk) {
@@ -634,20 +631,8 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
         // the 32 gradient values of this lane's channel are fetched up front: the run-boundary branches below would
         // otherwise serialise every record on an LDS round trip; then the stage is free for the next block
         float gr[32];
-        if (sizeof(T) == 2) {
-          // bf16 -> f32 is "the 16 bits in the upper half of a zero dword": ds_read_u16_d16_hi does exactly that while it loads
-          // (it preserves the lower half, zero since the initialisation of gbits[]), so a record needs no unpack instruction.
-          // The compiler does not select that load from C++ (it emits ds_read_u16 + v_perm); it is issued by hand, and because
-          // its counter accounting does not see these 32 loads, the uses below wait on lgkmcnt explicitly (LDS returns in order;
-          // the field holds 0..15, a wait for fewer outstanding operations than necessary only over-waits).
-          const uint32_t lds0 = (uint32_t)(uintptr_t)stage + (uint32_t)lane * 2u;
 #pragma unroll
-          for (int k = 0; k < 32; ++k)
-            asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "+v"(gbits[k]) : "v"(lds0), "n"(k * 128) : "memory");
-        } else {
-#pragma unroll
-          for (int k = 0; k < 32; ++k) gr[k] = Ld1<T>::ld(stage + k * 64 + lane);
-        }
+        for (int k = 0; k < 32; ++k) gr[k] = Ld1<T>::ld(stage + k * 64 + lane);
         if (blk + 1 < nb) { MSDA_GATHER(blk + 1) }
         // bilinear corner coefficients of record i0 + (lane & 31), zero for the corners that lie outside this tile
         f32x2_t cT, cB;
@@ -660,15 +645,6 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
           const float wt = ly >= 0 ? w * (1.f - ay) : 0.f, wb = ly < MSDA_TH - 1 ? w * ay : 0.f;
           cT = f32x2_t{wt * wl, wt * wr};
           cB = f32x2_t{wb * wl, wb * wr};
-        }
-        // bf16 storage path: the two coefficients of a corner pair travel as ONE dword of two bf16 (round-to-nearest-even), so a
-        // record costs two v_readlane instead of four and the unpacking is scalar-ALU work (shift / mask of a wave-uniform
-        // value), which issues beside the vector ALU this kernel is bound by.  The 2^-9 coefficient rounding is of the size of
-        // the bf16 rounding of d_value itself; the fp32 path keeps the exact coefficients.
-        uint32_t pT = 0, pB = 0;
-        if (sizeof(T) == 2) {
-          pT = (uint32_t)f2bf(cT.x) | ((uint32_t)f2bf(cT.y) << 16);
-          pB = (uint32_t)f2bf(cB.x) | ((uint32_t)f2bf(cB.y) << 16);
         }
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
@@ -686,22 +662,10 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
               run_end = __builtin_amdgcn_readfirstlane(s_start[min(cls + 1, MSDA_NCLS + 1)]);
             } while (i0 + k == run_end);
           }
-          float g;
-          if (sizeof(T) == 2) {
-            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(31 - k < 15 ? 31 - k : 15) : "memory");
-            g = __uint_as_float(gbits[k]);
-          } else {
-            g = gr[k];
-          }
+          const float g = gr[k];
           const f32x2_t g2 = {g, g};
-          if (sizeof(T) == 2) {
-            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)pT, k), sb = (uint32_t)__builtin_amdgcn_readlane((int)pB, k);
-            accT += f32x2_t{__uint_as_float(st << 16), __uint_as_float(st & 0xffff0000u)} * g2;
-            accB += f32x2_t{__uint_as_float(sb << 16), __uint_as_float(sb & 0xffff0000u)} * g2;
-          } else {
-            accT += f32x2_t{readlane_f(cT.x, k), readlane_f(cT.y, k)} * g2;
-            accB += f32x2_t{readlane_f(cB.x, k), readlane_f(cB.y, k)} * g2;
-          }
+          accT += f32x2_t{readlane_f(cT.x, k), readlane_f(cT.y, k)} * g2;
+          accB += f32x2_t{readlane_f(cB.x, k), readlane_f(cB.y, k)} * g2;
         }
         if (blk + 1 < nb) { MSDA_PARK() }
       }
