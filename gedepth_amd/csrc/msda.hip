@@ -610,38 +610,30 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
       if (n + lane < nb * 32 && lane < 32) { s_key[n + lane] = 0; s_w[n + lane] = 0.f; s_ax[n + lane] = 0.f; s_ay[n + lane] = 0.f; }
       __builtin_amdgcn_wave_barrier();
 
-      // ---- gather (the rows of the next TWO blocks in flight while this one is consumed: the kernel waits on the L2 misses of
-      //      these gathers, not on its arithmetic) + run-wise accumulation.  Two register sets alternate by block parity.
-      u32x4_t RA[NR], RB[NR];                              // (HIP's uint4 struct kept such arrays in scratch)
-#define MSDA_GATHER(R_, BLK)                                                                               \
+      // ---- gather (next block in flight while this one is consumed) + run-wise accumulation
+      u32x4_t R[NR];                                       // (HIP's uint4 struct kept this array in scratch)
+#define MSDA_GATHER(BLK)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                                         \
     const int q = s_key[(BLK) * 32 + i * RPI + gi] >> 7;                                                   \
-    R_[i] = *(const u32x4_t*)(gout + (rowbase + (long)q * nH) * 64 + subc);                                \
+    R[i] = *(const u32x4_t*)(gout + (rowbase + (long)q * nH) * 64 + subc);                                 \
   }
-#define MSDA_PARK(R_)                                                                                      \
-  _Pragma("unroll") for (int i = 0; i < NR; ++i) *(u32x4_t*)(stage + (i * RPI + gi) * 64 + subc) = R_[i];
+#define MSDA_PARK()                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < NR; ++i) *(u32x4_t*)(stage + (i * RPI + gi) * 64 + subc) = R[i];
       // a0[p] += v for a wave-uniform p, only when `ok` (a branch around it makes the compiler copy all 32 registers)
 #define MSDA_PUT(P_, OK_, V_) a0[(P_) & 31] += (OK_) ? (V_) : 0.f
       int cls = 0;
       int run_end = __builtin_amdgcn_readfirstlane(s_start[1]);
       f32x2_t accT = {0.f, 0.f}, accB = {0.f, 0.f};        // top pair (ly: lx, lx+1), bottom pair (ly+1: lx, lx+1)
-      MSDA_GATHER(RA, 0)
-      MSDA_PARK(RA)
-      if (nb > 1) { MSDA_GATHER(RA, 1) }
-      for (int blk0 = 0; blk0 < nb; blk0 += 2) {
-#pragma unroll
-       for (int par = 0; par < 2; ++par) {                  // par is a constant in each copy: RA / RB are named statically
-        const int blk = blk0 + par;
-        if (blk >= nb) break;
-        u32x4_t (&Rhold)[NR] = par ? RB : RA;              // holds the rows of block blk + 1
-        u32x4_t (&Rget)[NR] = par ? RA : RB;               // receives the rows of block blk + 2
+      MSDA_GATHER(0)
+      MSDA_PARK()
+      for (int blk = 0; blk < nb; ++blk) {
         const int i0 = blk * 32;
         // the 32 gradient values of this lane's channel are fetched up front: the run-boundary branches below would
         // otherwise serialise every record on an LDS round trip; then the stage is free for the next block
         float gr[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) gr[k] = Ld1<T>::ld(stage + k * 64 + lane);
-        if (blk + 2 < nb) { MSDA_GATHER(Rget, blk + 2) }
+        if (blk + 1 < nb) { MSDA_GATHER(blk + 1) }
         // bilinear corner coefficients of record i0 + (lane & 31), zero for the corners that lie outside this tile
         f32x2_t cT, cB;
         {
@@ -675,8 +667,7 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
           accT += f32x2_t{readlane_f(cT.x, k), readlane_f(cT.y, k)} * g2;
           accB += f32x2_t{readlane_f(cB.x, k), readlane_f(cB.y, k)} * g2;
         }
-        if (blk + 1 < nb) { MSDA_PARK(Rhold) }
-       }
+        if (blk + 1 < nb) { MSDA_PARK() }
       }
       {                                                      // close the last open class: all four corners
         const int ly = cls / 9 - 1, lx = cls % 9 - 1;
