@@ -646,9 +646,14 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
           cT = f32x2_t{wt * wl, wt * wr};
           cB = f32x2_t{wb * wl, wb * wr};
         }
+        // the wave's own instruction stream is what this kernel is bound by: the run boundary is tested against
+        // a block-relative value (compare with a constant), and the four wave-uniform coefficients of record k + 1 are read
+        // while record k is accumulated, so that no hazard nops separate a v_readlane from the FMA that uses its SGPR
+        int rel = run_end - i0;
+        float nTx = readlane_f(cT.x, 0), nTy = readlane_f(cT.y, 0), nBx = readlane_f(cB.x, 0), nBy = readlane_f(cB.y, 0);
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-          if (__builtin_expect(i0 + k == run_end, 0)) {      // wave-uniform and rare: keep the hot path fall-through
+          if (__builtin_expect(k == rel, 0)) {               // wave-uniform and rare: keep the hot path fall-through
             do {                                             // leave class `cls` (and any empty classes behind it)
               const int ly = cls / 9 - 1, lx = cls % 9 - 1;
               const bool in_cls = cls < MSDA_NCLS;
@@ -660,12 +665,17 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
               accB = f32x2_t{carry ? accB.y : 0.f, 0.f};
               ++cls;
               run_end = __builtin_amdgcn_readfirstlane(s_start[min(cls + 1, MSDA_NCLS + 1)]);
-            } while (i0 + k == run_end);
+              rel = run_end - i0;
+            } while (k == rel);
+          }
+          const f32x2_t kT = {nTx, nTy}, kB = {nBx, nBy};
+          if (k + 1 < 32) {
+            nTx = readlane_f(cT.x, k + 1); nTy = readlane_f(cT.y, k + 1); nBx = readlane_f(cB.x, k + 1); nBy = readlane_f(cB.y, k + 1);
           }
           const float g = gr[k];
           const f32x2_t g2 = {g, g};
-          accT += f32x2_t{readlane_f(cT.x, k), readlane_f(cT.y, k)} * g2;
-          accB += f32x2_t{readlane_f(cB.x, k), readlane_f(cB.y, k)} * g2;
+          accT += kT * g2;
+          accB += kB * g2;
         }
         if (blk + 1 < nb) { MSDA_PARK() }
       }
