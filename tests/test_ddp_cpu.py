@@ -383,3 +383,29 @@ def test_grad_arena_adopts_autograd_gradients():
     before = arena.flat_grad.clone()
     arena.collect()
     assert torch.equal(before, arena.flat_grad)
+
+
+def test_bf16_shadow_serves_only_current_values():
+    """``lowp`` hands out the optimizer's bf16 shadow view while it reflects the parameter (refresh after the write) and a plain
+    cast after any other in-place write (checkpoint load, broadcast through the parameter, init) until the next refresh."""
+    from gedepth_amd.mmrt.optim import lowp
+    torch.manual_seed(0)
+    model = Toy()
+    arena = GradArena(model.parameters())
+    p = arena.params[0]
+    assert lowp(p, torch.bfloat16).data_ptr() != p.data_ptr() and not hasattr(p, '_ge_lp')       # no shadow: a cast
+    arena.enable_shadow()
+    assert lowp(p, torch.bfloat16).data_ptr() != p._ge_lp.data_ptr()                             # allocated but not yet filled
+    arena.refresh_shadow(copy=True)
+    for q in arena.params:
+        s = lowp(q, torch.bfloat16)
+        assert s.data_ptr() == q._ge_lp.data_ptr() and s.shape == q.shape and torch.equal(s, q.detach().to(torch.bfloat16))
+        assert lowp(q, torch.float32) is q
+    with torch.no_grad():
+        p.mul_(2.0)
+    stale = lowp(p, torch.bfloat16)
+    assert stale.data_ptr() != p._ge_lp.data_ptr() and torch.equal(stale, p.detach().to(torch.bfloat16))
+    arena.flat_param.mul_(0.5)                                    # a write through the arena does not touch tensor versions ...
+    arena.refresh_shadow(copy=True)                               # ... so whoever does it refreshes (FusedAdamW, FlatDDP broadcast)
+    assert lowp(p, torch.bfloat16).data_ptr() == p._ge_lp.data_ptr()
+    assert torch.equal(p._ge_lp, p.detach().to(torch.bfloat16))
