@@ -382,7 +382,9 @@ struct MsdaWs {            // device workspace carved by the host wrapper
 //   COUNT: hist[head*ntiles + tile]++ in LDS, then the histogram is stored to seg_hist[b][seg][.] and added to cnt[bin]
 //   FILL : LDS cursors start at the segment's exclusive offsets (seg_hist rewritten in place by msda_segscan_k) and
 //          hand out slots: records[slot] = {query << 7 | (ly+1) << 4 | (lx+1), weight, frac x, frac y}
+#ifndef MSDA_SEG
 #define MSDA_SEG 65536
+#endif
 template <bool FILL>
 __global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
                                                    const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P, int nseg, int B,
