@@ -18,7 +18,9 @@
 #include "msda.h"
 #include <limits.h>
 
+#ifndef MW_BYTES
 #define MW_BYTES 51200                    // LDS window: 400 bf16 rows / 200 fp32 rows of 64 channels; 3 workgroups per CU
+#endif
 #define MW_QPG 4                          // queries per lane group (accumulators live in registers across the level loop)
 
 struct MsdaQGrid {                        // query tiling: segments of (H, W) queries in raster order (the levels for
