@@ -155,6 +155,26 @@ template <> struct MwAcc<bf16_t> {
     }
   }
 };
+// bf16 forward with the four tap weights rounded to bf16 and travelling as two bf16x2 dwords (w00 | w01, w10 | w11): per dword of
+// a value row (two channels) two v_perm pair the corners up per channel and two v_dot2_f32_bf16 accumulate them — 8 instead of 16
+// vector instructions per dword, and two shuffles per point instead of four.  The products are exact and the sums fp32; what is
+// given up is 2^-9 relative on each tap weight, below the bf16 rounding of the output the path ends in (fp32 path: exact weights).
+__device__ __forceinline__ void mw_fma4_packed(float* acc, const uint4& a, const uint4& b, const uint4& c, const uint4& d, uint32_t wab,
+                                               uint32_t wcd) {
+  const uint32_t ra[4] = {a.x, a.y, a.z, a.w}, rb[4] = {b.x, b.y, b.z, b.w}, rc[4] = {c.x, c.y, c.z, c.w}, rd[4] = {d.x, d.y, d.z, d.w};
+  const bf16x2_t vab = __builtin_bit_cast(bf16x2_t, wab), vcd = __builtin_bit_cast(bf16x2_t, wcd);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t ab_lo = __builtin_amdgcn_perm(rb[i], ra[i], 0x05040100u), ab_hi = __builtin_amdgcn_perm(rb[i], ra[i], 0x07060302u);
+    const uint32_t cd_lo = __builtin_amdgcn_perm(rd[i], rc[i], 0x05040100u), cd_hi = __builtin_amdgcn_perm(rd[i], rc[i], 0x07060302u);
+    float lo = acc[2 * i], hi = acc[2 * i + 1];
+    lo = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ab_lo), vab, lo, false);
+    hi = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ab_hi), vab, hi, false);
+    lo = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, cd_lo), vcd, lo, false);
+    hi = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, cd_hi), vcd, hi, false);
+    acc[2 * i] = lo; acc[2 * i + 1] = hi;
+  }
+}
 template <> struct MwAcc<float> {
   static __device__ __forceinline__ void fma4(float* acc, const uint4& a, const uint4& b, const uint4& c, const uint4& d,
                                               float w00, float w01, float w10, float w11) {
@@ -238,7 +258,15 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
           const int k = __shfl(pk[i], p, G);
-          const float a = __shfl(w00[i], p, G), b = __shfl(w01[i], p, G), c = __shfl(w10[i], p, G), d = __shfl(w11[i], p, G);
+          const bool packed = sizeof(T) == 2;              // bf16 storage path: see mw_fma4_packed
+          float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+          uint32_t wab = 0, wcd = 0;
+          if (packed) {
+            wab = (uint32_t)__shfl((int)((uint32_t)f2bf(w00[i]) | ((uint32_t)f2bf(w01[i]) << 16)), p, G);
+            wcd = (uint32_t)__shfl((int)((uint32_t)f2bf(w10[i]) | ((uint32_t)f2bf(w11[i]) << 16)), p, G);
+          } else {
+            a = __shfl(w00[i], p, G); b = __shfl(w01[i], p, G); c = __shfl(w10[i], p, G); d = __shfl(w11[i], p, G);
+          }
           const int i00 = k & 0x3fffffff, dx = (k >> 30) & 1;
           const int i10 = i00 + ((k >> 31) & rstride);
           uint4 r00, r01, r10, r11;
@@ -249,7 +277,8 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
             r00 = gsrc[mul24(i00, s16)]; r01 = gsrc[mul24(i00 + dx, s16)];
             r10 = gsrc[mul24(i10, s16)]; r11 = gsrc[mul24(i10 + dx, s16)];
           }
-          MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, a, b, c, d);
+          if (packed) mw_fma4_packed(acc[i], r00, r01, r10, r11, wab, wcd);
+          else MwAcc<T>::fma4(acc[i], r00, r01, r10, r11, a, b, c, d);
         }
       }
     } else {
