@@ -239,8 +239,15 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
 // d_loc / d_attw only (the binned path computes d_value separately): same 16-lane-group decomposition as the forward
 // kernel (4 channels per lane, one 16-byte / 8-byte load per tap and lane, four (query, head) pairs per wave), the three
 // per-point sums reduced over the group with a 4-step butterfly.
+// Occupancy target of the d_loc / d_attw kernel, measured A/B in one session (cross / self launch, ms): compiler default (94 VGPRs,
+// 5 waves per SIMD) 6.09 / 2.00; 8 waves 8.70 / 2.84 (spills); 6: 6.25 / 2.09; **4: 5.67 / 1.87**; 3: 5.77 / 1.95; 2: 6.07 / 2.15 —
+// with 128 registers the compiler keeps the row gathers of more sampling points in flight.
+#ifndef MSDA_LW_WAVES
+#define MSDA_LW_WAVES 4
+#endif
+#define MSDA_LW_ATTR __attribute__((amdgpu_waves_per_eu(MSDA_LW_WAVES, MSDA_LW_WAVES)))
 template <typename T, bool HM>
-__global__ void __launch_bounds__(256) msda_bwd_lw_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
+__global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
                                                      const float* __restrict__ attw, const T* __restrict__ gout,
                                                      float* __restrict__ d_loc, float* __restrict__ d_attw, long n_groups,
                                                      int Nv, int Nq, int nH, int L, int P) {
