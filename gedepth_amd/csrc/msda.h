@@ -94,6 +94,25 @@ static inline int msda_levels(const int* spatial_hw, int L, int Nv, MsdaLevels& 
 }
 
 
+// ---- d_value by binning (msda.hip: count / scan / fill / drain; msda_drain_mfma.hip: the bf16 MFMA drain)
+#define MSDA_TW 8
+#define MSDA_TH 4
+#define MSDA_TILE 32           // positions per bin = one 32-register accumulator block per lane
+#define MSDA_CHUNK 4096
+typedef float f32x32_t __attribute__((ext_vector_type(32)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; int ntx[MSDA_MAX_L]; };   // tiles of level l: [first_tile[l], first_tile[l+1]), ntx per row
+
+struct MsdaWs {            // device workspace carved by the host wrapper
+  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int4* entries;   // ctrl[0] = total chunks, ctrl[2+x] = next chunk of XCD x's share
+};
+
+// bf16 drain of the binned d_value on the matrix cores (msda_drain_mfma.hip); tr = use ds_read_b64_tr_b16 for the B operand
+int msda_drain_mfma_launch(const MsdaLevels& lv, const MsdaBins& bins, const MsdaWs& ws, const void* gout, float* d_value, int nbins,
+                           int Nv, int Nq, int nH, int L, bool tr, hipStream_t s);
+
+
 // LDS-window kernels (msda_win.hip); query geometry = n_qseg (H, W) segments of queries in raster order
 int msda_win_supported(int B, int Nq, int nH, int L, int P, int Nv);
 int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc, const float* attw,

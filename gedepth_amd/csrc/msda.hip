@@ -370,18 +370,7 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
 // ONE gradient row, and with a 2-D tile they share one tile 71 % of the time: a record is a (point, tile) pair — 1.41 per
 // point on average instead of 4 (point, corner) entries — so the drain gathers 2.8x fewer gradient rows and the record
 // list is 22.6 instead of 32 bytes per point.
-#define MSDA_TW 8
-#define MSDA_TH 4
-#define MSDA_TILE 32           // positions per bin = one 32-register accumulator block per lane
-#define MSDA_CHUNK 4096
-typedef float f32x32_t __attribute__((ext_vector_type(32)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; int ntx[MSDA_MAX_L]; };   // tiles of level l: [first_tile[l], first_tile[l+1]), ntx per row
-
-struct MsdaWs {            // device workspace carved by the host wrapper
-  int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int4* entries;   // ctrl[0] = total chunks, ctrl[2+x] = next chunk of XCD x's share
-};
+// (tile geometry, MsdaBins and MsdaWs: msda.h — shared with the MFMA drain in msda_drain_mfma.hip)
 
 // Binning = a counting sort with workgroup-private LDS histograms (global integer atomics cost one L2 request per
 // lane: 8e8 of them took 45-70 ms; LDS counters are private to the CU).  grid = (segments, batch): a workgroup owns
@@ -759,10 +748,11 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
 // Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry), bit 2 =
 // owner-lane tap arithmetic in the window kernels, bit 3 = head-major work order in the streaming kernels; the
 // streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
-static int g_msda_mode = 13;       // window forward + owner-lane taps + head-major streaming d_loc/d_attw (measured best)
+// bit 4 = bf16 d_value drain on the matrix cores (msda_drain_mfma.hip), bit 5 = its B operand through ds_read_b64_tr_b16.
+static int g_msda_mode = 13 | 16 | 32;   // window forward + owner-lane taps + head-major streaming d_loc/d_attw + MFMA drain (measured best)
 extern "C" int ge_msda_mode(int mode) {
   const int old = g_msda_mode;
-  if (mode >= 0) g_msda_mode = mode & 15;
+  if (mode >= 0) g_msda_mode = mode & 63;
   return old;
 }
 
@@ -818,6 +808,7 @@ extern "C" int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, in
 // default; when off the entry point records nothing and never synchronises.
 #define MSDA_NSTAGE 5
 static bool g_msda_lw_win_used = false;
+static bool g_msda_drain_mfma_used = false;
 static const char* const kMsdaStage[MSDA_NSTAGE] = {"msda_bwd_lw_k", "msda_hist_k<false>", "msda_scan_k+msda_segscan_k",
                                                     "msda_hist_k<true>", "msda_drain_k"};
 struct MsdaStageRec { int stage; hipEvent_t a, b; };
@@ -864,7 +855,7 @@ extern "C" int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launch
   msda_flush_locked();
   *total_ms = g_msda_ms[stage];
   *launches = g_msda_n[stage];
-  const char* nm = (stage == 0 && g_msda_lw_win_used) ? "msda_bwd_lw_win_k" : kMsdaStage[stage];
+  const char* nm = (stage == 0 && g_msda_lw_win_used) ? "msda_bwd_lw_win_k" : (stage == 4 && g_msda_drain_mfma_used) ? "msda_drain_mfma_k" : kMsdaStage[stage];
   if (name && name_cap > 0) { strncpy(name, nm, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
   return GE_OK;
 }
@@ -938,9 +929,13 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B, pl.hsplit);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 4, s);
+  g_msda_drain_mfma_used = dtype == GE_BF16 && (g_msda_mode & 16);
   if (dtype == GE_F32)
     msda_drain_k<float><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const float*)d_out, d_value, nbins, Nv, Nq, nH, L);
-  else
+  else if (g_msda_drain_mfma_used) {
+    e = msda_drain_mfma_launch(lv, bins, ws, d_out, d_value, nbins, Nv, Nq, nH, L, (g_msda_mode & 32) != 0, s);
+    if (e) return e;
+  } else
     msda_drain_k<bf16_t><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)d_out, d_value, nbins, Nv, Nq, nH, L);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 5, s);

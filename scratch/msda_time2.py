@@ -49,7 +49,7 @@ for name, qshapes in (('cross', [(H // 2, W // 2)]), ('self', shapes)):
     aw = torch.rand(B, Nq, 8, 32, device=dev).softmax(-1).view(B, Nq, 8, 4, 8).requires_grad_(True)
     go = torch.randn(B, Nq, 512, device=dev).bfloat16()
     res = {}
-    for mode in ([int(m) for m in os.environ['MODES'].split(',')] if os.environ.get('MODES') else (7, 13, 8, 0)):
+    for mode in ([int(m) for m in os.environ['MODES'].split(',')] if os.environ.get('MODES') else (13, 61, 29)):
         msda_mode(mode)
         for it in range(4):
             if it == 1:
@@ -57,13 +57,13 @@ for name, qshapes in (('cross', [(H // 2, W // 2)]), ('self', shapes)):
             out = ms_deform_attn(value, shapes, loc, aw, query_shapes=qshapes)
             out.backward(go)
             if it == 3:
-                res[mode] = (out.detach().float(), loc.grad.clone(), aw.grad.clone())
+                res[mode] = (out.detach().float(), loc.grad.clone(), aw.grad.clone(), value.grad.float().clone())
             value.grad = loc.grad = aw.grad = None
         kernels.PROFILER.disable()
         for r in kernels.PROFILER.summary() + kernels.PROFILER.msda_bwd_stages():
             print(f'{name:5s} mode {mode} {r["name"]:48s} {r["avg_us"] / 1e3:8.3f} ms')
-    for i, n in enumerate(('out', 'd_loc', 'd_attw')):
-        if 7 not in res or 0 not in res:
-            break
-        a, b = res[7][i], res[0][i]
-        print(f'{name} {n}: max |win - stream| = {(a - b).abs().max().item():.3e} (scale {b.abs().max().item():.3e})')
+    modes = list(res)
+    for m in modes[1:]:
+        for i, n in enumerate(('out', 'd_loc', 'd_attw', 'd_value')):
+            a, b = res[m][i], res[modes[0]][i]
+            print(f'{name} {n}: max |mode {m} - mode {modes[0]}| = {(a - b).abs().max().item():.3e} (scale {b.abs().max().item():.3e})')

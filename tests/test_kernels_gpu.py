@@ -324,10 +324,13 @@ def test_msda_window_kernels(dev, case, dtype):
     win_plain = run(3, qshapes)                             # window kernels, per-lane tap arithmetic
     stream = run(0, qshapes)
     stream_hm = run(8, qshapes)                             # streaming kernels, head-major work order
-    default = run(13, qshapes)                              # the default mix: window forward, streaming head-major backward
+    mix = run(13, qshapes)                                  # window forward, streaming head-major backward, VALU drain
+    default = run(61, qshapes)                              # the default: the same + bf16 d_value drain on MFMA (transposing LDS reads)
+    mfma_plain = run(29, qshapes)                           # MFMA drain with plain 16-bit LDS reads for the B operand
     names = ('out', 'd value', 'd loc', 'd attw')
     # same arithmetic per (query, head): the decompositions agree to the order of the 8-lane / 16-lane reductions
-    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major'), (default, 'default mode 13')):
+    for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major'), (mix, 'mode 13'),
+                   (default, 'default mode 61'), (mfma_plain, 'mode 29')):
         for a, b, n in zip(w, stream, names):
             if dtype == 'f32':
                 close_scaled(a, b, rel=2e-5, what=f'{tag} vs streaming: {n}')
@@ -392,7 +395,7 @@ def test_msda_bf16(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', [13, 0, 8, 7])
+@pytest.mark.parametrize('mode', [61, 29, 13, 0, 8, 7])
 @pytest.mark.parametrize('binned', [True, False])
 def test_msda_bf16_gradients_vs_oracle(dev, mode, binned, monkeypatch):
     """bf16 storage path against the fp32 CPU oracle evaluated on the SAME bf16-rounded value / gradient rows: d_loc and d_attw are
@@ -420,6 +423,35 @@ def test_msda_bf16_gradients_vs_oracle(dev, mode, binned, monkeypatch):
     close_scaled(vg.grad.float(), vc.grad, rel=1e-2, what='bf16 d value')
     close_scaled(ag.grad, ac.grad, rel=2e-5, what='bf16 d attw')
     close_scaled(lg.grad, lc.grad, rel=2e-4, what='bf16 d loc')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [61, 29, 13])
+def test_msda_drain_many_records_per_tile(dev, mode):
+    """d_value when a value tile collects far more than one chunk of records (4096): 4000 queries x 8 points land on a level of
+    2 x 4 tiles, so every bin is drained by several waves whose partial tiles meet through fp32 atomics; the last block of a
+    chunk is ragged.  bf16 storage: the MFMA drain (mode bit 4; bit 5 = ds_read_b64_tr_b16 operand reads) and the VALU drain
+    against the fp32 oracle on the same bf16-rounded rows."""
+    from gedepth_amd import kernels
+    from gedepth_amd.kernels import ms_deform_attn, msda_mode
+    shapes = ((8, 16), (4, 8), (2, 4), (1, 2))
+    value, loc, aw, go, shapes = _msda_inputs(11, B=2, Nq=4001, shapes=shapes)
+    vb, gb = value.bfloat16(), go.bfloat16()
+    vc = vb.float().requires_grad_(True)
+    ref = O.msda_core(vc, shapes, loc, aw)
+    ref.backward(gb.float())
+    old = msda_mode(mode)
+    try:
+        vg = vb.to(dev).requires_grad_(True)
+        kernels.PROFILER.enable()
+        out = ms_deform_attn(vg, shapes, loc.to(dev), aw.to(dev))
+        out.backward(gb.to(dev))
+        kernels.PROFILER.disable()
+        stages = [r['name'] for r in kernels.PROFILER.msda_bwd_stages()]
+    finally:
+        msda_mode(old)
+    assert ('msda_drain_mfma_k' if mode & 16 else 'msda_drain_k') in stages, stages
+    close_scaled(vg.grad.float(), vc.grad, rel=1e-2, what=f'bf16 d value, mode {mode}')
 
 
 def test_msda_module_golden(dev, golden):
