@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) slope_class_ddad_k(const float* __restric
     if (r > 5.0) r = 5.0;
     if (r < -5.0) r = -5.0;
     int16_t out = (int16_t)r;
-    if (!(r == r)) out = 0;
+    if (!(r == r)) out = -5;           // NaN: the reference's astype(np.int64) yields INT64_MIN on x86, which its clamp turns into -5
     if (g == 0.f) out = 255;
     cls[idx] = out;
   }

@@ -373,99 +373,88 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
 // (tile geometry, MsdaBins and MsdaWs: msda.h — shared with the MFMA drain in msda_drain_mfma.hip)
 
 // Binning = a counting sort with workgroup-private LDS histograms (global integer atomics cost one L2 request per
-// lane: 8e8 of them took 45-70 ms; LDS counters are private to the CU).  grid = (segments, batch): a workgroup owns
-// MSDA_SEG consecutive sampling points of one image, one point per lane per iteration (perfectly coalesced loc / attw).
-//   COUNT: hist[head*ntiles + tile]++ in LDS, then the histogram is stored to seg_hist[b][seg][.] and added to cnt[bin]
-//   FILL : LDS cursors start at the segment's exclusive offsets (seg_hist rewritten in place by msda_segscan_k) and
+// lane: 8e8 of them took 45-70 ms; LDS counters are private to the CU).  A work unit = (image, head, one of R contiguous
+// ranges of the queries); a workgroup of 1024 threads walks its unit's sampling points, one per lane per iteration (the
+// 32 points of a (query, head) are 256 contiguous bytes of loc).
+//   COUNT: hist[tile]++ in LDS, then the histogram is stored to seg_hist[unit][.] and added to cnt[bin]
+//   FILL : LDS cursors start at the unit's exclusive offsets (seg_hist rewritten in place by msda_segscan_k) and
 //          hand out slots: records[slot] = {query << 7 | (ly+1) << 4 | (lx+1), weight, frac x, frac y}
-#ifndef MSDA_SEG
-#define MSDA_SEG 65536
-#endif
+// Why few, large units (round 3; before: 65536-point segments over all heads, ~1000 workgroups resident): every
+// (unit, bin) pair owns a contiguous run of record slots that the unit fills 16 bytes at a time, so the set of partially
+// written 128-byte lines is (#resident units x #bins of a unit).  With 1000 units x 8800 bins that was 1.1 GB — every line left
+// the caches several times before it was complete and the fill pass ran at the speed of partial-line writes to HBM: 3.56 ms for the
+// cross-attention against 1.36 ms with the stores removed and 1.67 ms with the same bytes stored linearly (scratch experiment,
+// DESIGN.md §5).  One unit per CU and one head per unit leaves 256 x 1100 lines = 36 MB, which the L2s + the 256 MB Infinity Cache hold.
 template <bool FILL>
-__global__ void __launch_bounds__(256) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
-                                                   const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P, int nseg, int B,
-                                                   int hsplit) {
-  // hsplit == 1: the workgroup's LDS histogram covers all heads ([nH * ntiles] counters).  hsplit == nH (large maps, e.g.
-  // 1216 x 1936: 6e3 tiles x 8 heads would not fit): one workgroup per (segment, head) with [ntiles] counters, visiting only
-  // that head's (query, head) groups of the segment — still L*P consecutive points, i.e. coalesced.
+__global__ void __launch_bounds__(1024) msda_hist_k(MsdaLevels lv, MsdaBins bins, const float* __restrict__ loc,
+                                                    const float* __restrict__ attw, MsdaWs ws, int Nq, int nH, int L, int P, int R, int B) {
   extern __shared__ int hist[];
   const int ntiles = bins.first_tile[L];
-  const int nloc = nH * ntiles;
   const int LP = L * P;
-  const long vb = msda_xcd_block(blockIdx.x, gridDim.x);        // neighbouring segments (same value tiles) share an XCD
-  if (vb >= (long)nseg * B * hsplit) return;
-  const int hsel = (int)(vb % hsplit);
-  const long sb = vb / hsplit;
-  const int b = (int)(sb / nseg), seg = (int)(sb - (long)b * nseg);
-  const long npts_b = (long)Nq * nH * LP;
-  const int nwg = hsplit == 1 ? nloc : ntiles;            // counters of this workgroup
-  const int wg0 = hsplit == 1 ? 0 : hsel * ntiles;        // ... starting at this bin of the (batch, segment) histogram
-  int* gh = ws.seg_hist + ((long)b * nseg + seg) * nloc + wg0;
-  for (int i = threadIdx.x; i < nwg; i += 256) hist[i] = FILL ? gh[i] : 0;
-  __syncthreads();
-  const long p_lo = (long)seg * MSDA_SEG, p_hi = min(npts_b, p_lo + MSDA_SEG);    // MSDA_SEG is a multiple of L * P
-  const long g_lo = p_lo / LP, g_hi = p_hi / LP;          // (query, head) groups of the segment
-  const long g_first = hsplit == 1 ? g_lo : g_lo + ((hsel - g_lo % nH) + nH) % nH;
-  const long g_step = hsplit == 1 ? 1 : nH;
-  const long n_local = g_first < g_hi ? ((g_hi - g_first + g_step - 1) / g_step) * LP : 0;
-  // per-point index arithmetic in 32 bits with shifts when L*P, P and nH are powers of two (every GEDepth config): a 64-bit
-  // division by a run-time value is ~50 VALU instructions, and this loop has one thread per sampling point
-  const int sh_lp = (LP & (LP - 1)) ? -1 : __ffs(LP) - 1, sh_p = (P & (P - 1)) ? -1 : __ffs(P) - 1, sh_h = (nH & (nH - 1)) ? -1 : __ffs(nH) - 1;
-  const int n_loc32 = (int)n_local, gstep32 = (int)g_step;           // n_local <= MSDA_SEG
-  const long ib0 = g_first * LP;
-  const int gstep_lp = gstep32 * LP;
-  for (int j = threadIdx.x; j < n_loc32; j += 256) {
-    const int jg = sh_lp >= 0 ? (j >> sh_lp) : j / LP;
-    const int lp = j - mul24(jg, LP);
-    const long grp_l = g_first + mul24(jg, gstep32);
-    const int grp_b = (int)grp_l;                        // q*nH + head
-    const long ib = ib0 + mul24(jg, gstep_lp) + lp;
-    const int l = sh_p >= 0 ? (lp >> sh_p) : lp / P;
-    const int q = sh_h >= 0 ? (grp_b >> sh_h) : grp_b / nH, head = grp_b - mul24(q, nH);
-    const int Hl = lv.H[l], Wl = lv.W[l];
-    const long pt = (long)b * npts_b + ib;
-    const float2 xy = ((const float2*)loc)[pt];
-    const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;
-    if (!(y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl)) continue;
-    const float xf = floorf(x), yf = floorf(y);
-    const int x0 = (int)xf, y0 = (int)yf;
-    const float ax = x - xf, ay = y - yf;
-    const float wgt = FILL ? attw[pt] : 0.f;
-    const int ntx = bins.ntx[l];
-    const int lb0 = mul24(head, ntiles) + bins.first_tile[l] - wg0;
-    // tile columns / rows that hold an in-image corner: the left column x0 (if >= 0) and the right column x0+1 (if < W)
-    const bool xa = x0 >= 0, xb = x0 + 1 < Wl, ya = y0 >= 0, yb = y0 + 1 < Hl;
-    const int txa = x0 >> 3, txb = (x0 + 1) >> 3, tya = y0 >> 2, tyb = (y0 + 1) >> 2;
-    const int tx_first = xa ? txa : txb, ty_first = ya ? tya : tyb;
-    const int two_x = (xa && xb && txb != txa) ? 1 : 0, two_y = (ya && yb && tyb != tya) ? 1 : 0;
-    for (int jy = 0; jy <= two_y; ++jy)
-      for (int jx = 0; jx <= two_x; ++jx) {
-        const int tx = jx ? txb : tx_first, ty = jy ? tyb : ty_first;
-        const int slot = atomicAdd(&hist[lb0 + mul24(ty, ntx) + tx], 1);        // LDS
-        if (FILL) {
-          const int lx1 = x0 - tx * MSDA_TW + 1, ly1 = y0 - ty * MSDA_TH + 1;   // top-left corner relative to the tile, +1: [0,8] x [0,4]
-          ws.entries[slot] = make_int4((q << 7) | (ly1 << 4) | lx1, __float_as_int(wgt), __float_as_int(ax), __float_as_int(ay));
-        }
-      }
-  }
-  if (!FILL) {
+  const int nunits = B * nH * R;
+  // per-point index arithmetic in 32 bits with shifts when L*P and P are powers of two (every GEDepth config): a division by a
+  // run-time value is ~50 VALU instructions, and this loop has one thread per sampling point
+  const int sh_lp = (LP & (LP - 1)) ? -1 : __ffs(LP) - 1, sh_p = (P & (P - 1)) ? -1 : __ffs(P) - 1;
+  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {          // u = (b * nH + head) * R + r
+    const int r = u % R, bh = u / R;
+    const int head = bh % nH, b = bh / nH;
+    int* gh = ws.seg_hist + (long)u * ntiles;
+    for (int i = threadIdx.x; i < ntiles; i += 1024) hist[i] = FILL ? gh[i] : 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < nwg; i += 256) {
-      const int c = hist[i];
-      gh[i] = c;
-      if (c) atomicAdd(&ws.cnt[b * nloc + wg0 + i], c);
+    const int q_lo = (int)((long)Nq * r / R), q_hi = (int)((long)Nq * (r + 1) / R);
+    const int n = (q_hi - q_lo) * LP;                              // launcher: (Nq / R + 1) * LP < 2^31
+    const long pt0 = ((long)b * Nq + q_lo) * nH + head;            // (b, q, head) group of the unit's first query
+    for (int j = threadIdx.x; j < n; j += 1024) {
+      const int qi = sh_lp >= 0 ? (j >> sh_lp) : j / LP;
+      const int lp = j - mul24(qi, LP);
+      const int l = sh_p >= 0 ? (lp >> sh_p) : lp / P;
+      const int q = q_lo + qi;
+      const long pt = (pt0 + (long)qi * nH) * LP + lp;
+      const int Hl = lv.H[l], Wl = lv.W[l];
+      const float2 xy = ((const float2*)loc)[pt];
+      const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;
+      if (!(y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl)) continue;
+      const float xf = floorf(x), yf = floorf(y);
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float ax = x - xf, ay = y - yf;
+      const float wgt = FILL ? attw[pt] : 0.f;
+      const int ntx = bins.ntx[l];
+      const int lb0 = bins.first_tile[l];
+      // tile columns / rows that hold an in-image corner: the left column x0 (if >= 0) and the right column x0+1 (if < W)
+      const bool xa = x0 >= 0, xb = x0 + 1 < Wl, ya = y0 >= 0, yb = y0 + 1 < Hl;
+      const int txa = x0 >> 3, txb = (x0 + 1) >> 3, tya = y0 >> 2, tyb = (y0 + 1) >> 2;
+      const int tx_first = xa ? txa : txb, ty_first = ya ? tya : tyb;
+      const int two_x = (xa && xb && txb != txa) ? 1 : 0, two_y = (ya && yb && tyb != tya) ? 1 : 0;
+      for (int jy = 0; jy <= two_y; ++jy)
+        for (int jx = 0; jx <= two_x; ++jx) {
+          const int tx = jx ? txb : tx_first, ty = jy ? tyb : ty_first;
+          const int slot = atomicAdd(&hist[lb0 + mul24(ty, ntx) + tx], 1);        // LDS
+          if (FILL) {
+            const int lx1 = x0 - tx * MSDA_TW + 1, ly1 = y0 - ty * MSDA_TH + 1;   // top-left corner relative to the tile, +1: [0,8] x [0,4]
+            ws.entries[slot] = make_int4((q << 7) | (ly1 << 4) | lx1, __float_as_int(wgt), __float_as_int(ax), __float_as_int(ay));
+          }
+        }
+    }
+    __syncthreads();
+    if (!FILL) {
+      for (int i = threadIdx.x; i < ntiles; i += 1024) {
+        const int c = hist[i];
+        gh[i] = c;
+        if (c) atomicAdd(&ws.cnt[bh * ntiles + i], c);
+      }
+      __syncthreads();
     }
   }
 }
 
-// seg_hist[b][seg][i] (counts) -> absolute first slot of segment `seg` in bin b*nloc+i
-__global__ void __launch_bounds__(256) msda_segscan_k(MsdaWs ws, int nloc, int nseg, int B) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)B * nloc) return;
-  const int b = (int)(i / nloc), li = (int)(i - (long)b * nloc);
+// seg_hist[unit = bh * R + r][tile] (counts) -> absolute first slot of unit r in bin bh * ntiles + tile
+__global__ void __launch_bounds__(256) msda_segscan_k(MsdaWs ws, int ntiles, int R, int nbins) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbins) return;
+  const int bh = i / ntiles, tile = i - bh * ntiles;
   int run = (int)ws.offset[i];
-  int* p = ws.seg_hist + (long)b * nseg * nloc + li;
-  for (int sgm = 0; sgm < nseg; ++sgm) { const int c = p[(long)sgm * nloc]; p[(long)sgm * nloc] = run; run += c; }
+  int* p = ws.seg_hist + (long)bh * R * ntiles + tile;
+  for (int r = 0; r < R; ++r) { const int c = p[(long)r * ntiles]; p[(long)r * ntiles] = run; run += c; }
 }
 
 __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
@@ -717,20 +706,28 @@ static size_t msda_ws_layout(int nbins, long seg_hist_ints, long max_entries, ch
   }
   return off;
 }
-struct MsdaPlan { int ntiles, nloc, nseg, nbins, hsplit; long max_entries; bool ok; };
+struct MsdaPlan { int ntiles, nloc, R, nbins; long max_entries; bool ok; };
+// Work units of the counting sort = resident 1024-thread workgroups: two per CU (2048 threads, the CU's limit).  Measured, cross /
+// self launch (ms): 128 units count 1.56 / 0.53, fill 3.54 / 1.15; 256: 0.81 / 0.28, 2.47 / 0.73; 512: 0.55 / 0.19, 2.17 / 0.73;
+// 1024 = 512 (only 512 are resident).  The passes wait on memory latency, so threads in flight are what counts.
+#ifndef MSDA_HIST_WGS
+#define MSDA_HIST_WGS 512
+#endif
 static MsdaPlan msda_plan(const MsdaBins& bins, int B, int Nq, int nH, int L, int P) {
   MsdaPlan pl;
   pl.ntiles = bins.first_tile[L];
   pl.nloc = nH * pl.ntiles;
   const long npts_b = (long)Nq * nH * L * P;
-  pl.nseg = (int)((npts_b + MSDA_SEG - 1) / MSDA_SEG);
+  // query ranges per (image, head): enough units for one per CU, each with at least a few thousand points
+  long R = (MSDA_HIST_WGS + (long)B * nH - 1) / std::max(1L, (long)B * nH);
+  R = std::max(1L, std::min(R, (long)std::max(1, Nq / 64)));
+  pl.R = (int)R;
   pl.max_entries = (long)B * npts_b * 4;
   const long nbins = (long)B * pl.nloc;
   pl.nbins = (int)nbins;
-  pl.hsplit = (size_t)pl.nloc * 4 <= 60 * 1024 ? 1 : nH;                     // LDS histogram per workgroup: all heads, or one
-  const size_t hist_bytes = (size_t)(pl.hsplit == 1 ? pl.nloc : pl.ntiles) * 4;
+  const size_t hist_bytes = (size_t)pl.ntiles * 4;
   pl.ok = nbins < (1L << 30) && Nq < (1 << 24) && pl.max_entries < (1L << 31) && hist_bytes <= 60 * 1024 && B <= 65535 &&
-          MSDA_SEG % (L * P) == 0 && (long)B * pl.nseg * pl.hsplit < (1L << 30);
+          ((long)Nq / R + 1) * L * P < (1L << 31) && (long)B * nH * R * pl.ntiles < (1L << 31);
   return pl;
 }
 static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
@@ -785,12 +782,12 @@ extern "C" size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, in
   msda_bins(lv, L, bins);
   const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
   if (!pl.ok) return 0;
-  return msda_ws_layout(pl.nbins, (long)B * pl.nseg * pl.nloc, pl.max_entries, nullptr, nullptr);
+  return msda_ws_layout(pl.nbins, (long)B * nH * pl.R * pl.ntiles, pl.max_entries, nullptr, nullptr);
 }
 
 // Which backward path ge_msda_bwd takes for a geometry (introspection for tests / DESIGN tables; no device work):
-// out[0] = 1 binned (workspace) path available, out[1] = histogram split (1 = all heads per workgroup, nH = one head per
-// workgroup: maps too large for one LDS histogram, e.g. 1216 x 1936), out[2] = value tiles, out[3] = bins.
+// out[0] = 1 binned (workspace) path available, out[1] = query ranges per (image, head) of the counting sort (its work units are
+// (image, head, range); the LDS histogram of a unit holds one head's tiles), out[2] = value tiles, out[3] = bins.
 extern "C" int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int* out4) {
   MsdaLevels lv;
   if (!spatial_hw || !out4) return GE_ERR_BAD_ARG;
@@ -799,7 +796,7 @@ extern "C" int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, in
   MsdaBins bins;
   msda_bins(lv, L, bins);
   const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
-  out4[0] = pl.ok ? 1 : 0; out4[1] = pl.hsplit; out4[2] = pl.ntiles; out4[3] = pl.nbins;
+  out4[0] = pl.ok ? 1 : 0; out4[1] = pl.R; out4[2] = pl.ntiles; out4[3] = pl.nbins;
   return GE_OK;
 }
 
@@ -883,7 +880,7 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   MsdaBins bins;
   msda_bins(lv, L, bins);
   const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
-  const long seg_ints = (long)B * pl.nseg * pl.nloc;
+  const long seg_ints = (long)B * nH * pl.R * pl.ntiles;
   const bool binned = workspace && pl.ok && workspace_bytes >= msda_ws_layout(pl.nbins, seg_ints, pl.max_entries, nullptr, nullptr);
   if (!binned) {
     if (dtype == GE_F32) MSDA_BWD_P(float, true); else MSDA_BWD_P(bf16_t, true);
@@ -916,17 +913,17 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   msda_ws_layout(nbins, seg_ints, pl.max_entries, (char*)workspace, &ws);
   hipError_t he = hipMemsetAsync(ws.cnt, 0, (size_t)nbins * 4, s);
   if (he != hipSuccess) return (int)he;
-  const unsigned hgrid = msda_grid((long)pl.nseg * B * pl.hsplit, 1);
-  const size_t hsmem = (size_t)(pl.hsplit == 1 ? pl.nloc : pl.ntiles) * 4;
-  msda_hist_k<false><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B, pl.hsplit);
+  const unsigned hgrid = (unsigned)std::min((long)MSDA_HIST_WGS, (long)B * nH * pl.R);
+  const size_t hsmem = (size_t)pl.ntiles * 4;
+  msda_hist_k<false><<<hgrid, 1024, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.R, B);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 2, s);
   msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
   GE_LAUNCH_CHECK();
-  msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.nloc, pl.nseg, B);
+  msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.ntiles, pl.R, nbins);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 3, s);
-  msda_hist_k<true><<<hgrid, 256, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.nseg, B, pl.hsplit);
+  msda_hist_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.R, B);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 4, s);
   g_msda_drain_mfma_used = dtype == GE_BF16 && (g_msda_mode & 16);

@@ -37,7 +37,9 @@ def train_depther(model, dataset, cfg, distributed=False, validate=False, timest
     if cfg.get('runner') is None:
         cfg.runner = dict(type='IterBasedRunner', max_iters=cfg.total_iters)
     assert cfg.runner['type'] == 'IterBasedRunner'
-    amp = torch.bfloat16 if cfg.get('amp', 'bf16') == 'bf16' else None
+    # numerics follow the config: the reference trains in fp32 (fp16_enabled = False, depth/models/depther/base.py:20), so a
+    # reference config run through this drop-in stays fp32; bf16 autocast is an explicit choice (cfg.amp = 'bf16' / --bf16)
+    amp = torch.bfloat16 if cfg.get('amp', 'fp32') == 'bf16' else None
     runner = IterBasedRunner(wrapped, optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta,
                              max_iters=cfg.runner['max_iters'], amp_dtype=amp)
     runner.batch_transform = batch_transform

@@ -46,14 +46,14 @@ class _Profiler:
                                 total_ms=total.value, bytes_per_launch=self.stage_bytes.get(i, 0) / n.value))
         return out
 
-    def run(self, name, nbytes, call):
+    def run(self, name, nbytes, call, flops=0):
         if not self.on:
             return call()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = call()
         e.record()
-        rec = self.records.setdefault(name, dict(bytes=int(nbytes), events=[]))
+        rec = self.records.setdefault(name, dict(bytes=int(nbytes), flops=int(flops), events=[]))
         rec['events'].append((s, e))
         return r
 
@@ -65,7 +65,7 @@ class _Profiler:
         for name, rec in self.records.items():
             ms = [s.elapsed_time(e) for s, e in rec['events']]
             out.append(dict(name=name, launches=len(ms), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
-                            bytes_per_launch=rec['bytes']))
+                            bytes_per_launch=rec['bytes'], flops_per_launch=rec.get('flops', 0)))
         return out
 
 
@@ -102,10 +102,12 @@ class _WindowAttention(torch.autograd.Function):
         bias_table = _c(bias_table.detach().to(_f32))
         out = torch.empty(B, L, C3 // 3, device=qkv.device, dtype=qkv.dtype)
         nbytes = 4 * B * L * (C3 // 3) * _es(qkv) + 169 * num_heads * 4
+        n_wh = B * ((H + 6) // 7) * ((W + 6) // 7) * num_heads            # (window, head) pairs; 2 contractions of 2*49*49*32 flops each
         PROFILER.run(f'window_attn_fwd[{B}x{H}x{W} nH{num_heads} s{shift} {_tag(qkv)} v{variant}]', nbytes, lambda: hip.check(
             hip.lib().ge_window_attn_fwd(
                 hip.ptr(qkv, name='qkv'), hip.ptr(qkv_bias, _f32), hip.ptr(bias_table, _f32), hip.ptr(out),
-                B, H, W, num_heads, shift, scale, hip.dtype_code(qkv), variant, hip.stream()), 'ge_window_attn_fwd'))
+                B, H, W, num_heads, shift, scale, hip.dtype_code(qkv), variant, hip.stream()), 'ge_window_attn_fwd'),
+            flops=n_wh * 2 * 2 * 49 * 49 * 32)
         ctx.save_for_backward(qkv, qkv_bias, bias_table)
         ctx.geom = (B, H, W, num_heads, shift, scale, variant)
         return out
@@ -121,11 +123,12 @@ class _WindowAttention(torch.autograd.Function):
         lib = hip.lib()
         ws = torch.empty(max(int(lib.ge_window_attn_bwd_workspace(B, H, W, nH)), 4) // 4, device=qkv.device, dtype=_f32)
         nbytes = 7 * qkv.numel() // 3 * _es(qkv)
+        n_wh = B * ((H + 6) // 7) * ((W + 6) // 7) * nH                     # backward: S, dP, dQ, dK, dV = 5 contractions
         PROFILER.run(f'window_attn_bwd[{B}x{H}x{W} nH{nH} s{shift} {_tag(qkv)} v{variant}]', nbytes, lambda: hip.check(
             lib.ge_window_attn_bwd(
                 hip.ptr(qkv), hip.ptr(qkv_bias), hip.ptr(bias_table), hip.ptr(d_out), hip.ptr(d_qkv), hip.ptr(d_qb),
                 hip.ptr(d_tab), hip.ptr(ws), B, H, W, nH, shift, scale, hip.dtype_code(qkv), variant, hip.stream()),
-            'ge_window_attn_bwd'))
+            'ge_window_attn_bwd'), flops=n_wh * 5 * 2 * 49 * 49 * 32)
         return d_qkv, d_qb, d_tab, None, None, None, None, None, None
 
 
@@ -152,8 +155,10 @@ def _query_grid(query_shapes, Nq):
 
 
 def msda_mode(mode=-1):
-    """Kernel-selection knob of the deformable-attention ops (bit 0: window forward, bit 1: window d_loc/d_attw); returns
-    the previous mode."""
+    """Kernel-selection knob of the deformable-attention ops; returns the previous mode.  Bits: 0 window (LDS-staged) forward,
+    1 window d_loc / d_attw, 2 owner-lane tap arithmetic in the window kernels, 3 head-major work order of the streaming kernels,
+    4 bf16 d_value drain on MFMA, 5 its operand reads through ds_read_b64_tr_b16.  Default 61; ``GE_MSDA_MODE`` in the environment
+    sets it at library load (e.g. 60: streaming forward with exact fp32 tap weights for accuracy-parity runs in bf16)."""
     return int(hip.lib().ge_msda_mode(int(mode)))
 
 
@@ -211,7 +216,12 @@ class _MSDeformAttn(torch.autograd.Function):
 def ms_deform_attn(value, spatial_shapes, sampling_locations, attention_weights, query_shapes=None):
     """value (B,Nv,nH,64), loc (B,Nq,nH,L,P,2) in [0,1], attw (B,Nq,nH,L,P) -> (B,Nq,nH*64).
     ``query_shapes``: the queries as a list of (H, W) maps in raster order (sum H*W == Nq) — lets the kernels tile them 2-D
-    and sample from LDS-staged value windows (csrc/msda_win.hip); None = streaming kernels.  Same results either way."""
+    and sample from LDS-staged value windows (csrc/msda_win.hip); None = streaming kernels.
+    fp32: the same results either way (to the order of the lane reductions, 2e-5 of the tensor scale).  bf16 storage: the window
+    forward rounds the four tap weights (already multiplied by the attention weight) to bf16 — 2^-9 relative per tap, below the
+    bf16 rounding of the output it ends in (measured: within one bf16 ulp of the streaming kernel, which keeps fp32 weights like
+    mmcv) — and the MFMA drain rounds the d_value coefficients the same way; d_loc / d_attw always use exact fp32 weights.
+    ``msda_mode`` / ``GE_MSDA_MODE`` select the exact-weight kernels (tests compare both)."""
     return _MSDeformAttn.apply(value, sampling_locations, attention_weights, spatial_shapes, query_shapes)
 
 

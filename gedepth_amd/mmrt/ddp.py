@@ -63,6 +63,11 @@ class FlatDDP(nn.Module):
         self._works = []
         self._next = 0
         self._hooks = []
+        # GE_DDP_TRACE=1: per-bucket launch / completion times of the latest step (ms since the first gradient hook of the step;
+        # HIP events on the launching stream for device tensors, host clock otherwise) — makes the overlap of the exchange with
+        # backward readable off a single-GPU run with GE_DDP_FORCE=1 (``bucket_trace()``)
+        self.trace_on = os.environ.get('GE_DDP_TRACE') == '1'
+        self._trace, self.last_trace = [], []
         if self.active:
             for idx, p in enumerate(arena.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
@@ -73,11 +78,26 @@ class FlatDDP(nn.Module):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._works, self._next = [], 0
         self._streams = [set() for _ in self.buckets]       # HIP streams on which a bucket's gradients were accumulated
+        self._trace, self._t0 = [], None
+
+    def _stamp(self):
+        if self.arena.flat_grad.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time
+        return time.perf_counter()
+
+    def bucket_trace(self):
+        """[{bucket, bytes, params, launch_ms, done_ms}] of the latest finished step (needs GE_DDP_TRACE=1)."""
+        return list(self.last_trace)
 
     def _make_hook(self, idx):
         def hook(param):
             b = self.bucket_of[idx]
             self._pending[b] -= 1
+            if self.trace_on and self._t0 is None:
+                self._t0 = self._stamp()
             if param.is_cuda:                                 # branches of the model may run (forward and backward) on side streams
                 self._streams[b].add(torch.cuda.current_stream(param.device))
             if self.overlap:
@@ -94,6 +114,11 @@ class FlatDDP(nn.Module):
         if hasattr(self.arena, 'collect'):
             self.arena.collect(members)                       # gradients autograd handed over -> this bucket's arena slice
         buf = self.arena.flat_grad[lo:hi]
+        if self.trace_on:
+            if self._t0 is None:
+                self._t0 = self._stamp()
+            self._trace.append(dict(bucket=b, bytes=(hi - lo) * (2 if self.grad_dtype is not None else 4), params=len(members),
+                                    launch=self._stamp()))
         if self.grad_dtype is not None:                       # reduced-precision exchange through a staging buffer
             stage = buf.to(self.grad_dtype)
             work = dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -117,14 +142,29 @@ class FlatDDP(nn.Module):
         while self._next < len(self.buckets):            # parameters without a gradient this step, or overlap off
             self._launch(self._next)
             self._next += 1
-        for work, post in self._works:
+        for i, (work, post) in enumerate(self._works):
             work.wait()
+            if self.trace_on:
+                self._trace[i]['done'] = self._stamp()
             if post is not None:
                 kind, buf, stage = post
                 if kind == 'widen':
+                    # `stage` may have been allocated on a side stream (the hook of a branch that ran there launched this bucket):
+                    # tell the caching allocator that the current stream reads it, or the block could be handed out again while
+                    # the widen kernel is still queued
+                    if stage.is_cuda:
+                        stage.record_stream(torch.cuda.current_stream(stage.device))
                     torch.mul(stage, 1.0 / self.world, out=buf)          # bf16 -> fp32 with the averaging scale, one pass
                 else:
                     buf.div_(self.world)
+        if self.trace_on and self._trace:
+            if self.arena.flat_grad.is_cuda:
+                torch.cuda.synchronize(self.arena.flat_grad.device)
+                rel = lambda t: self._t0.elapsed_time(t)
+            else:
+                rel = lambda t: (t - self._t0) * 1e3
+            self.last_trace = [dict(bucket=r['bucket'], bytes=r['bytes'], params=r['params'], launch_ms=rel(r['launch']),
+                                    done_ms=rel(r['done'])) for r in self._trace]
         self._reset()
 
     # ------------------------------------------------------------------ module protocol

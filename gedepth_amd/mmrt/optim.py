@@ -94,7 +94,13 @@ class GradArena:
         return self.flat_shadow
 
     def refresh_shadow(self, copy=True):
-        """Mark the shadow current (after the optimizer kernel wrote it) or rebuild it from the fp32 arena (``copy``)."""
+        """Mark the shadow current (after the optimizer kernel wrote it) or rebuild it from the fp32 arena (``copy``).
+
+        INVARIANT: ``lowp`` trusts the shadow while ``p._version`` is unchanged.  Writes that do not bump that counter —
+        ``p.data.copy_ / mul_``, writes through ``arena.flat_param`` (EMA, a manual broadcast, initialisation after
+        ``build_optimizer``), raw-pointer kernels — leave the shadow stale until the next optimizer step: call
+        ``refresh_shadow(copy=True)`` after any such out-of-band parameter write.  The runner does so at ``before_run`` and after a
+        resume, ``FlatDDP`` after its parameter broadcast."""
         if getattr(self, 'flat_shadow', None) is None:
             return
         if copy:
@@ -219,8 +225,15 @@ class FusedAdamW(torch.optim.Optimizer):
                 if tuple(state_dict[k].shape) != (self.arena.numel,):
                     raise ValueError(f'optimizer {k}: arena of {tuple(state_dict[k].shape)} elements, this model needs {self.arena.numel}')
             self.step_count = int(state_dict['step'])
-            self.exp_avg.copy_(state_dict['exp_avg'].to(self.exp_avg.device, torch.float32))
-            self.exp_avg_sq.copy_(state_dict['exp_avg_sq'].to(self.exp_avg.device, torch.float32))
+            # round-1 arenas stored EVERY slice in the parameter's logical (NCHW) order; today a channels-last conv weight keeps
+            # its slice in NHWC order (GradArena._view).  Copy slice by slice through the view, so that a moment lands on the
+            # element it belongs to whatever the layout of this run (a 1:1 arena copy would permute the moments of every conv
+            # weight with more than one input channel, silently).
+            for k, buf in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                src = state_dict[k].to(buf.device, torch.float32)
+                buf.zero_()
+                for p, (off, n) in zip(self.arena.params, self.arena.slices()):
+                    GradArena._view(buf, off, p).copy_(src[off:off + n].view(p.shape))
             for g, s in zip(self.param_groups, state_dict['param_groups']):
                 g.update({k: v for k, v in s.items() if k != 'params'})
             return

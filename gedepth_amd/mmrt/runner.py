@@ -136,13 +136,32 @@ class EvalHook(Hook):
     """Every ``interval`` iterations run ``evaluate_fn(runner) -> dict`` and keep the best checkpoint by
     ``save_best`` with rule less/greater (depth/core/evaluation/eval_hooks.py:9-118, configs :152-159)."""
 
-    def __init__(self, evaluate_fn, interval=800, by_epoch=False, save_best=None, rule='less', start=0, **kwargs):
+    def __init__(self, evaluate_fn, interval=800, by_epoch=False, save_best=None, rule='less', start=0, broadcast_bn_buffer=True,
+                 **kwargs):
         self.evaluate_fn, self.interval, self.save_best, self.rule, self.start = evaluate_fn, interval, save_best, rule, start
+        self.broadcast_bn_buffer = broadcast_bn_buffer
         self.best = None
+
+    @staticmethod
+    def broadcast_bn_buffers(model):
+        """BatchNorm statistics stay per GPU during training (no SyncBN, like the reference); before a distributed evaluation
+        rank 0's running_var / running_mean are broadcast so that every rank evaluates the same model
+        (depth/core/evaluation/eval_hooks.py:75-87).  Returns the number of BatchNorm modules touched."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 0
+        n = 0
+        for module in model.modules():
+            if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and module.track_running_stats:
+                dist.broadcast(module.running_var, 0)
+                dist.broadcast(module.running_mean, 0)
+                n += 1
+        return n
 
     def after_train_iter(self, runner):
         if not self.every_n_iters(runner, self.interval) or runner.iter + 1 < self.start:
             return
+        if self.broadcast_bn_buffer:
+            self.broadcast_bn_buffers(runner.model)
         metrics = self.evaluate_fn(runner)
         if runner.rank == 0 and metrics:
             runner.logger('Eval ' + ', '.join(f'{k}: {v:.4f}' for k, v in metrics.items()))
@@ -213,6 +232,7 @@ class IterBasedRunner:
         loader = data_loaders[0]
         device = next(self.model.parameters()).device
         self.model.train()
+        self._refresh_shadow()                  # parameters may have been written out of band since build_optimizer (init, load_from)
         self.call_hook('before_run')
         # mmcv IterLoader semantics: an epoch counter that re-seeds the DistributedSampler on every restart of the loader
         # (without set_epoch every epoch replays the same permutation and per-rank shard); on resume it is derived from
@@ -253,9 +273,16 @@ class IterBasedRunner:
         model = self.model.module if hasattr(self.model, 'module') else self.model
         return load_checkpoint(model, path, map_location, strict, logger=self.logger)
 
+    def _refresh_shadow(self):
+        """Rebuild the optimizer's bf16 parameter shadow from the fp32 arena (GradArena.refresh_shadow's invariant)."""
+        arena = getattr(self.optimizer, 'arena', None)
+        if arena is not None and hasattr(arena, 'refresh_shadow'):
+            arena.refresh_shadow(copy=True)
+
     def resume(self, path, map_location='cpu'):
         ckpt = self.load_checkpoint(path, map_location)
         self.iter = ckpt.get('meta', {}).get('iter', 0)
         if 'optimizer' in ckpt:
             self.optimizer.load_state_dict(ckpt['optimizer'])
+        self._refresh_shadow()
         self.logger(f'resumed from {path} at iter {self.iter}')

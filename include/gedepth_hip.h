@@ -91,8 +91,8 @@ int ge_msda_mode(int mode);
  * (one integer atomic per tap, tiles accumulated in registers); with workspace == NULL the scatter falls back to
  * fp32 atomic bursts straight into d_value. */
 size_t ge_msda_bwd_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P);
-/* Introspection (no device work): out4 = {binned path available, histogram split (1 = all heads per workgroup,
- * nH = one head per workgroup for maps whose tile count exceeds one LDS histogram), value tiles, bins}. */
+/* Introspection (no device work): out4 = {binned path available, query ranges per (image, head) — the counting sort's
+ * work units are (image, head, query range), one 1024-thread workgroup each —, value tiles, bins}. */
 int ge_msda_bwd_plan(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int* out4);
 int ge_msda_bwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg,
                 const float* loc, const float* attw,

@@ -409,3 +409,123 @@ def test_bf16_shadow_serves_only_current_values():
     arena.refresh_shadow(copy=True)                               # ... so whoever does it refreshes (FusedAdamW, FlatDDP broadcast)
     assert lowp(p, torch.bfloat16).data_ptr() == p._ge_lp.data_ptr()
     assert torch.equal(p._ge_lp, p.detach().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------ world size 4: ragged buckets, late / missing gradients, trace
+class Branchy(nn.Module):
+    """Parameters whose gradients arrive OUT of registration order (the `late` head is registered first but used last in the
+    forward, so backward produces it first; `early` is registered last and produced last), one parameter that gets no gradient
+    on odd steps, and sizes that leave a ragged tail bucket."""
+
+    def __init__(self):
+        super().__init__()
+        self.late = nn.Linear(5, 1)                      # first in the arena -> LAST bucket (buckets are built from the end)
+        self.body = nn.Linear(7, 5)
+        self.skip = nn.Linear(7, 5)                      # unused on odd steps
+        self.early = nn.Linear(3, 7)                     # last in the arena -> FIRST bucket, but its gradient arrives last
+
+    def forward(self, x, use_skip):
+        h = self.early(x)
+        y = torch.tanh(self.body(h))
+        if use_skip:
+            y = y + self.skip(h)
+        return self.late(y)
+
+
+def _worker4(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GE_DDP_TRACE='1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(3 + rank)
+    model = Branchy()
+    arena = GradArena(model.parameters(), align=1, adopt=True)       # align 1: slice sizes 5,1,35,5,35,5,21,7 -> ragged buckets
+    ddp = FlatDDP(model, arena, bucket_mb=40 * 4 / 2 ** 20)          # 40 floats per bucket
+    sizes = [hi - lo for lo, hi, _ in ddp.buckets]
+    assert len(sizes) >= 3 and len(set(sizes)) > 1 and sum(sizes) == arena.numel, sizes
+    assert sizes[-1] < 40                                            # the tail bucket (front of the arena) is a partial one
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(16, 3, generator=g), torch.randn(16, 1, generator=g)
+    res = dict(sizes=sizes, grads=[], traces=[])
+    for step in range(3):
+        arena.zero_grad()
+        use_skip = step % 2 == 0
+        loss = (ddp(X[rank * 4:(rank + 1) * 4], use_skip) - Y[rank * 4:(rank + 1) * 4]).pow(2).mean()
+        loss.backward()
+        ddp.finish()
+        res['grads'].append(arena.flat_grad.clone())
+        res['traces'].append(ddp.bucket_trace())
+    res['params'] = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.save(res, os.path.join(tmp, f'w{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_gloo_world4_ragged_buckets_and_late_gradients(tmp_path):
+    """World size 4 (the N = 4 point of the driver's scaling run): buckets of unequal size with a partial tail bucket, gradients
+    that become ready out of bucket order (buckets must still launch strictly in sequence on every rank — a rank-dependent
+    order would deadlock or mix slices), a parameter without a gradient on some steps (its slice must be reduced as zeros),
+    three iterations through the state machine.  Every rank must end each step with the full-batch gradient."""
+    port = free_port()
+    mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    rs = [torch.load(tmp_path / f'w{i}.pt', weights_only=False) for i in range(4)]
+    ref = Branchy()
+    ref.load_state_dict(rs[0]['params'])
+    arena = GradArena(ref.parameters(), align=1, adopt=False)
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(16, 3, generator=g), torch.randn(16, 1, generator=g)
+    for step in range(3):
+        for r in rs[1:]:
+            assert torch.equal(r['grads'][step], rs[0]['grads'][step]), step
+        arena.flat_grad.zero_()
+        (ref(X, step % 2 == 0) - Y).pow(2).mean().backward()
+        assert torch.allclose(arena.flat_grad, rs[0]['grads'][step], rtol=1e-5, atol=1e-7), step
+        if step % 2 == 1:                                   # `skip` had no gradient: its slice is exactly zero after the exchange
+            off = arena.offsets[[id(p) for p in arena.params].index(id(ref.skip.weight))]
+            assert torch.count_nonzero(rs[0]['grads'][step][off:off + ref.skip.weight.numel()]) == 0
+    # the trace (GE_DDP_TRACE=1): one record per bucket and step, launched in bucket order, completion after launch
+    for r in rs:
+        for tr in r['traces']:
+            assert [t['bucket'] for t in tr] == list(range(len(r['sizes'])))
+            assert all(t['done_ms'] >= t['launch_ms'] >= 0 for t in tr)
+            assert [t['bytes'] for t in tr] == [4 * n for n in r['sizes']]
+
+
+class BNNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 4, 1)
+        self.bn = nn.BatchNorm2d(4)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+def _bn_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from gedepth_amd.mmrt.runner import EvalHook
+    torch.manual_seed(0)
+    net = BNNet().train()
+    net(torch.randn(8, 2, 5, 5, generator=torch.Generator().manual_seed(10 + rank)) * (1 + rank))     # per-rank statistics
+    before = (net.bn.running_mean.clone(), net.bn.running_var.clone())
+
+    import types
+    R = types.SimpleNamespace(model=net, iter=0, rank=rank, work_dir=tmp, logger=lambda *a: None)
+    seen = {}
+    hook = EvalHook(lambda runner: seen.update(mean=runner.model.bn.running_mean.clone(), var=runner.model.bn.running_var.clone()) or {},
+                    interval=1)
+    hook.after_train_iter(R)
+    torch.save(dict(before=before, seen=seen), os.path.join(tmp, f'bn{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eval_hook_broadcasts_bn_buffers_before_distributed_eval(tmp_path):
+    """depth/core/evaluation/eval_hooks.py:75-87: BatchNorm running statistics are per GPU during training; before a distributed
+    evaluation rank 0's are broadcast, so that every rank scores its shard with the same model."""
+    port = free_port()
+    mp.spawn(_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f'bn{i}.pt', weights_only=False) for i in range(2))
+    assert not torch.equal(r0['before'][0], r1['before'][0]) and not torch.equal(r0['before'][1], r1['before'][1])
+    for k, i in (('mean', 0), ('var', 1)):
+        assert torch.equal(r0['seen'][k], r0['before'][i])           # rank 0 keeps its own statistics
+        assert torch.equal(r1['seen'][k], r0['before'][i])           # rank 1 evaluates with rank 0's

@@ -347,8 +347,8 @@ def test_msda_window_kernels(dev, case, dtype):
 
 
 def test_msda_large_maps_use_per_head_histograms(dev):
-    """Value maps whose (heads x tiles) histogram exceeds one workgroup's LDS (native-resolution DDAD, config #4) take the
-    one-head-per-workgroup counting sort; same results as the oracle, and the workspace path is really taken."""
+    """Value maps with thousands of tiles (native-resolution DDAD, config #4): the counting sort's work units hold one head's
+    tiles in LDS (a histogram over all heads would not fit); same results as the oracle, and the workspace path is really taken."""
     from gedepth_amd import hip, kernels
     from gedepth_amd.kernels import ms_deform_attn
     import ctypes

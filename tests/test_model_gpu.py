@@ -167,6 +167,28 @@ def test_e2e_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
     f64 = f64k
     total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params.values())).item()
     assert abs(total - total64) <= 1e-4 * total64, (total, total64)
+    # ... and DIRECTLY against the gradients the reference itself produced (`grad::*` of the fixture: the reference's fp32 CPU
+    # backward, strided samples), at the bound the oracle is held to in tests/test_oracle_golden.py::test_e2e (2e-3 of the
+    # tensor's max magnitude; the gap is the kink decisions discussed above, on both sides), so that no link of
+    # reference -> oracle -> HIP is only transitive.
+    worst_fix = ('', 0.0)
+    n_fix = 0
+    for k in g.files:
+        if not k.startswith('grad::'):
+            continue
+        gr = params[k[6:]].grad.detach().float().cpu().flatten()
+        gr = gr[::max(1, gr.numel() // 50000)]
+        ref_g = T(g[k])
+        scale = ref_g.abs().max().item() + 1e-12
+        e = (gr - ref_g).abs().max().item() / scale
+        n_fix += 1
+        if e > worst_fix[1]:
+            worst_fix = (k[6:], e)
+    print(f'[{tag}] HIP gradients vs the reference fixture directly: {n_fix} tensors, worst max-abs / scale = {worst_fix[1]:.2e} ({worst_fix[0]})')
+    rec['grad_worst_vs_fixture'] = worst_fix[1]
+    _log_parity(tag, rec)
+    assert n_fix > 0 and worst_fix[1] <= 2e-3, worst_fix
+    assert abs(total - float(g['grad_norm_total'])) <= 1e-3 * float(g['grad_norm_total']), (total, float(g['grad_norm_total']))
 
 
 def test_full_size_forward_vs_oracle(dev):
@@ -274,8 +296,7 @@ def test_config2_bf16_full_shape_step_vs_fp32(dev):
 def test_config4_ddad_native_resolution_train_step(dev):
     """configs[3]: DepthFormer-SwinL + GEDepth-Adaptive at the native DDAD resolution 1x5x1216x1936 (per-camera height
     kwarg, loading.py:923-932): one full bf16 training step on the HIP path — finite losses, every parameter gets a finite
-    gradient, and the deformable-attention backward runs the binned path with ONE HEAD PER WORKGROUP histograms (the
-    6e3 value tiles x 8 heads of this map do not fit one LDS histogram)."""
+    gradient, and the deformable-attention backward runs the binned path (6e3 value tiles per head: 24 KB LDS histograms)."""
     import ctypes
     from gedepth_amd import hip
     from gedepth_amd.depth.datasets.synthetic import synthetic_batch
@@ -288,12 +309,12 @@ def test_config4_ddad_native_resolution_train_step(dev):
     nv = sum(h * w for h, w in shapes)
     hip.check(hip.lib().ge_msda_bwd_plan(ctypes.cast(arr, ctypes.c_void_p), 1, nv, (H // 2) * (W // 2), 8, 4, 8,
                                          ctypes.cast(out4, ctypes.c_void_p)), 'ge_msda_bwd_plan')
-    assert out4[0] == 1 and out4[1] == 8, list(out4)            # binned, per-head histograms
+    assert out4[0] == 1 and out4[1] == 64, list(out4)           # binned; 8 heads x 64 query ranges = 512 work units of the counting sort
     kitti4 = (ctypes.c_int * 4)()
     ks = [(88, 280), (44, 140), (22, 70), (11, 35)]
     hip.check(hip.lib().ge_msda_bwd_plan(ctypes.cast((ctypes.c_int * 8)(*[v for hw in ks for v in hw]), ctypes.c_void_p), 8, 32725,
                                          98560, 8, 4, 8, ctypes.cast(kitti4, ctypes.c_void_p)), 'ge_msda_bwd_plan')
-    assert kitti4[0] == 1 and kitti4[1] == 1, list(kitti4)      # KITTI shape: all heads in one histogram
+    assert kitti4[0] == 1 and kitti4[1] == 8, list(kitti4)      # KITTI shape, 8 images: 8 x 8 x 8 units
     torch.manual_seed(0)
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_a_ddad.py'))
     cfg.model.pretrained = None
@@ -318,6 +339,121 @@ def test_config4_ddad_native_resolution_train_step(dev):
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in model.parameters())
     print(f'\n[config #4 1x1216x1936 Swin-L-A bf16] losses {dict((k, round(v, 5)) for k, v in lv.items())}')
+
+
+def test_config3_swinl_adaptive_full_shape_bf16_step_vs_fp32(dev):
+    """configs[2] at its real per-GPU shape — DepthFormer-SwinL + GEDepth-Adaptive, 2 x 5 x 352 x 1120 (samples_per_gpu = 2 of
+    depthformer_a.py), bf16 autocast, channels-last, full step incl. the fused optimizer — against the fp32 step of the same model
+    on the same batch: both losses within the bf16 bound, gradient direction preserved globally and on each of the eight
+    sampling-offset / attention-weight projections (the tensors that only see d_loc / d_attw of the deformable attention)."""
+    from gedepth_amd import kernels
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.depth.models.utils import to_channels_last
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    kernels.FALLBACKS.clear()
+    torch.manual_seed(0)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_a.py'))
+    assert cfg.data.samples_per_gpu == 2 and cfg.model.backbone.embed_dims == 192 and 'dynamic_pe_neck' in cfg.model
+    model = build('depthformer_a.py')
+    model.init_weights()
+    model = model.to(dev).train()
+    to_channels_last(model)
+    batch = synthetic_batch(2, 352, 1120, seed=1234, device=dev)
+    ref = model.train_step(batch, None)                     # fp32 storage + arithmetic (exact-fp32 window attention)
+    ref['loss'].backward()
+    g32 = _grad_vector(model)
+    msda_names = [n for n, _ in model.named_parameters() if 'sampling_offsets' in n or 'attention_weights' in n]
+    named32 = {n: p.grad.detach().double().flatten().clone() for n, p in model.named_parameters() if n in msda_names}
+    for p in model.parameters():
+        p.grad = None
+    optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    optimizer.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model.train_step(batch, optimizer)
+    out['loss'].backward()
+    optimizer.arena.collect()
+    g16 = _grad_vector(model)
+    assert not kernels.FALLBACKS, f'modules fell back to ATen on the hot path: {kernels.FALLBACKS}'
+    cos = torch.nn.functional.cosine_similarity(g16.double(), g32.double(), dim=0).item()
+    nrm = (g16.norm() / g32.norm()).item()
+    rels = {k: abs(out['log_vars'][k] - v) / abs(v) for k, v in ref['log_vars'].items()}
+    worst = min(torch.nn.functional.cosine_similarity(p.grad.detach().double().flatten(), named32[n], dim=0).item()
+                for n, p in model.named_parameters() if n in msda_names)
+    print(f'\n[config #3 2x352x1120 Swin-L-A] losses fp32 {dict(ref["log_vars"])} bf16 {dict(out["log_vars"])}; grad cosine {cos:.5f}, '
+          f'|g_bf16|/|g_fp32| {nrm:.4f}, worst sampling-projection cosine {worst:.5f}')
+    _log_parity('config3_bf16_vs_fp32', dict(loss_rel=rels, grad_cosine=cos, grad_norm_ratio=nrm, worst_msda_projection_cosine=worst))
+    assert set(out['log_vars']) >= {'decode.loss_depth', 'decode.loss_dynamic_pe', 'loss'}
+    assert all(r <= 2e-2 for r in rels.values()), rels
+    assert torch.isfinite(g16).all() and cos >= 0.98 and 0.9 <= nrm <= 1.1 and worst >= 0.95, (cos, nrm, worst)
+    optimizer.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_config5_fp8_window_attention_workload(dev):
+    """configs[4] at the WORKLOAD level (the kernel-level bound is tests/test_kernels_gpu.py::test_window_attention_fp8_forward):
+    the whole model with every window attention on the fp8 (OCP e4m3) MFMA forward (`kernel_variant = 3`, bench.py --attn fp8),
+    (1) eval depth at 1 x 5 x 352 x 1120 against the exact-fp32 HIP path, with the bf16-MFMA attention model on the same weights as
+    the yardstick — the restated tolerance: fp8 attention may cost at most 3x the bf16 path's own error, and stays inside 5 % mean /
+    relative depth error; (2) one full 8 x 352 x 1120 bf16 training step (fp8 forward, bf16 backward kernels) against the bf16 step:
+    loss within 2 %, gradient cosine >= 0.9, every gradient finite, optimizer step finite."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    torch.manual_seed(0)
+    model = build('depthformer_swint_v.py')
+    model.init_weights()
+    model = model.to(dev)
+
+    def variant(v):
+        n = 0
+        for mod in model.modules():
+            if hasattr(mod, 'kernel_variant'):
+                mod.kernel_variant = v
+                n += 1
+        assert n == 12                                       # every Swin-T block
+
+    one = synthetic_batch(1, 352, 1120, seed=1234, device=dev)
+    model.eval()
+    with torch.no_grad():
+        variant(1)
+        d32 = model.encode_decode(one['img'], one['img_metas']).float()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            variant(0)
+            d16 = model.encode_decode(one['img'], one['img_metas']).float()
+            variant(3)
+            d8 = model.encode_decode(one['img'], one['img_metas']).float()
+    rel = lambda a: ((a - d32).abs() / d32.abs().clamp_min(1e-3))
+    e16, e8 = rel(d16), rel(d8)
+    print(f'\n[config #5 1x352x1120 eval] depth rel err vs fp32: bf16 attention mean {e16.mean().item():.2e} max {e16.max().item():.2e}; '
+          f'fp8 attention mean {e8.mean().item():.2e} max {e8.max().item():.2e}')
+    assert torch.isfinite(d8).all() and not torch.equal(d8, d16)                 # the fp8 kernels really ran
+    assert e8.mean().item() <= max(3.0 * e16.mean().item(), 1e-3) and e8.mean().item() <= 5e-2, (e8.mean().item(), e16.mean().item())
+    # ---- one full training step at the bench shape
+    model.train()
+    batch = synthetic_batch(8, 352, 1120, seed=1234, device=dev)
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    res = {}
+    for tag, v in (('bf16', 0), ('fp8', 3)):
+        variant(v)
+        optimizer.zero_grad()
+        torch.manual_seed(5)                                  # same DropPath / dropout draws in both runs
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = model.train_step(batch, optimizer)
+        out['loss'].backward()
+        optimizer.arena.collect()
+        res[tag] = (out['log_vars']['loss'], _grad_vector(model).clone())
+    (l16, g16), (l8, g8) = res['bf16'], res['fp8']
+    cos = torch.nn.functional.cosine_similarity(g8.double(), g16.double(), dim=0).item()
+    print(f'[config #5 8x352x1120 train step] loss bf16 {l16:.5f} fp8 {l8:.5f}; gradient cosine fp8 vs bf16 {cos:.4f}')
+    _log_parity('config5_fp8', dict(eval_mean_rel_bf16=e16.mean().item(), eval_mean_rel_fp8=e8.mean().item(), eval_max_rel_fp8=e8.max().item(),
+                                    loss_bf16=l16, loss_fp8=l8, grad_cosine=cos))
+    assert abs(l8 - l16) <= 2e-2 * abs(l16) and torch.isfinite(g8).all() and cos >= 0.9, (l16, l8, cos)
+    optimizer.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
 def test_ddad_per_camera_height_vs_oracle(dev):

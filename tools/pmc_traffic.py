@@ -9,8 +9,10 @@ profiles/pmc_traffic.json: HBM bytes per launch for every kernel of libgedepth_h
 
 Units / corrections (MI355X_MICROARCH.md, "HBM"): the counters are in KiB of memory-side L2 requests; on gfx950 their
 absolute scale depends on the access width, so both are calibrated on a kernel of this same run whose traffic is known
-exactly and exceeds the 256 MiB Infinity Cache: the fused AdamW step (reads p, g, m, v + a 1-byte decay mask and writes p, m, v:
-17 and 12 bytes per parameter).  The calibration factors are stored next to the numbers.
+exactly and exceeds the 256 MiB Infinity Cache: the fused AdamW step (reads p, g, m, v + a 1-byte decay mask = 17 bytes per
+parameter; writes p, m, v = 12 bytes per parameter, or 14 for the `adamw_k<true>` variant, which also writes the bf16 shadow copy
+of the parameters — round 2 calibrated WRITE_SIZE with 12 on that variant, so its write figures were 14 % low).  The calibration
+factors are stored next to the numbers, with a cross-check on `sumsq_k` (reads exactly 4 bytes per arena element).
 """
 import argparse
 import csv
@@ -61,9 +63,15 @@ def main():
         key = next((k for k in acc if k.startswith('adamw_k')), None)
         if key is None:
             raise SystemExit('calibration kernel adamw_k not in the trace')
+        if name == 'WRITE_SIZE' and 'true' in key:                      # adamw_k<true>: + the 2-byte bf16 shadow of every parameter
+            per_elem = 14
         reported = acc[key][0] / acc[key][1] * 1024.0
         cal[name] = dict(kernel=key, known_bytes=per_elem * a.adamw_elems, reported_bytes=reported,
                          factor=per_elem * a.adamw_elems / reported)
+    sk = next((k for k in fetch if k.startswith('sumsq_k')), None)
+    if sk is not None:                                                    # independent check of the FETCH factor
+        got = fetch[sk][0] / fetch[sk][1] * 1024.0 * cal['FETCH_SIZE']['factor']
+        cal['check_sumsq_k'] = dict(fetch_bytes=round(got), bytes_per_adamw_elem=got / a.adamw_elems)
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, [0.0, 0])

@@ -40,6 +40,8 @@ def main():
     p.add_argument('--gt', default=None, help='DDAD depth .npz (key "depth", float32)')
     p.add_argument('--out-k', default=None)
     a = p.parse_args()
+    if a.gt and not a.out_k:
+        p.error('--gt needs --out-k (where to write the slope classes)')
     c = np.load(a.calib)
     row2, num = plane_coefficients(c['intrinsics'], c['camera_pose'], c['lidar_pose'])
     pe64, _ = ground_plane(row2, num, a.size[0], a.size[1])

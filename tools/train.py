@@ -39,7 +39,8 @@ def parse_args():
     p.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--synthetic', type=int, default=0, help='train on N synthetic KITTI-shaped samples')
-    p.add_argument('--fp32', action='store_true', help='disable bf16 autocast')
+    p.add_argument('--bf16', action='store_true', help='bf16 autocast (fp32 master weights); default: the config\'s `amp`, else fp32 like the reference')
+    p.add_argument('--fp32', action='store_true', help='force fp32 even if the config sets amp = "bf16"')
     p.add_argument('--gpu-pipeline', action='store_true',
                    help='KITTI: loader workers only decode files; ground depth from the calibration and every transform of the train '
                         'pipeline run on the GPU (gedepth_amd/depth/datasets/gpu_pipeline.py, SURVEY.md §8 f3)')
@@ -60,6 +61,8 @@ def main():
         cfg.load_from = args.load_from
     if args.resume_from:
         cfg.resume_from = args.resume_from
+    if args.bf16:
+        cfg.amp = 'bf16'
     if args.fp32:
         cfg.amp = 'fp32'
     distributed = args.launcher != 'none'
