@@ -117,6 +117,14 @@ int msda_drain_mfma_launch(const MsdaLevels& lv, const MsdaBins& bins, const Msd
 int msda_win_supported(int B, int Nq, int nH, int L, int P, int Nv);
 int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc, const float* attw,
                         void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, bool pre, hipStream_t s);
+// raw projection inputs of the fused prepare + forward (msda_win.hip)
+struct MwRaw {
+  const void* off; long off_ld; const void* logit; long logit_ld;          // (B*Nq, ld) rows; columns (head, level, point[, xy])
+  const float* ref; long ref_sb, ref_sq, ref_sl;                             // reference points (B, Nq, L, 2), strides in elements
+  float* loc_out; float* attw_out;
+};
+int msda_fwd_win_raw_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const MwRaw& rw, void* out, int B,
+                            int Nv, int Nq, int nH, int L, int P, int dtype, hipStream_t s);
 int msda_bwd_lw_win_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const float* loc,
                            const float* attw, const void* gout, float* d_loc, float* d_attw, int B, int Nv, int Nq, int nH, int L,
                            int P, int dtype, bool pre, hipStream_t s);

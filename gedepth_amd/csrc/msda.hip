@@ -246,11 +246,17 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
 #define MSDA_LW_WAVES 4
 #endif
 #define MSDA_LW_ATTR __attribute__((amdgpu_waves_per_eu(MSDA_LW_WAVES, MSDA_LW_WAVES)))
-template <typename T, bool HM>
+// EMIT = true (L == 4, P == 8): the kernel writes the gradient of the RAW projection outputs instead of d_loc / d_attw —
+// d_off_raw = d_loc / (W_l, H_l) and d_logit_raw = attw * (d_attw - sum_{l,p} attw * d_attw) (mmcv's view / normaliser / softmax
+// backward, = msda_prep_bwd_k) — in the storage type: the fp32 d_loc / d_attw tensors (2.4 GB written and read back per
+// cross-attention launch) and the separate pass over them disappear.  d_loc leaves level by level; the 8 d_attw values of a level
+// sit in lanes 0-2 of the group after the reduce-scatter and wait in 12 registers for the sum over all 32 points.
+struct MsdaEmit { void* d_off; long off_ld; void* d_logit; long logit_ld; };
+template <typename T, bool HM, bool EMIT = false>
 __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __restrict__ value, MsdaLevels lv, const float* __restrict__ loc,
                                                      const float* __restrict__ attw, const T* __restrict__ gout,
                                                      float* __restrict__ d_loc, float* __restrict__ d_attw, long n_groups,
-                                                     int Nv, int Nq, int nH, int L, int P) {
+                                                     int Nv, int Nq, int nH, int L, int P, MsdaEmit em = MsdaEmit()) {
   constexpr int CPL = Lanes<T>::CPL, G = 64 / CPL;         // 16-byte loads: 16 lanes (fp32) / 8 lanes (bf16) per group
   const int sub = threadIdx.x % G;
   const int c0 = sub * CPL;
@@ -297,6 +303,7 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
       const float s_dy = bx * (d10 - d00) + ax * (d11 - d01);                                             \
       sv_ = s_val; sx_ = s_dx * (wgt * (float)Wl); sy_ = s_dy * (wgt * (float)Hl);                        \
     }
+    float ka[4];                                      // EMIT: d_attw of point `sub` at each level (static indices: the branches below are uniform)
     for (int l = 0; l < L; ++l) {
       const int Hl = lv.H[l], Wl = lv.W[l];
       const T* vl = vb + (long)lv.start[l] * nH * 64;
@@ -327,6 +334,25 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
 #pragma unroll
           for (int k = 0; k < 3; ++k) part[k] += __shfl_xor(part[k], 1, 64);
         }
+        if constexpr (EMIT) {
+          {   // the 8 d_attw sums (idx 0..7) sit three per holder lane: hand idx j to lane j of the group (one register per level)
+            const int src = (sub & ~(G - 1)) + (sub < 8 ? sub / 3 : 0) * (G / 8);
+            const float q0 = __shfl(part[0], src, G), q1 = __shfl(part[1], src, G), q2 = __shfl(part[2], src, G);
+            const int r3 = sub % 3;
+            const float mine = r3 == 0 ? q0 : r3 == 1 ? q1 : q2;
+            if (l == 0) ka[0] = mine; else if (l == 1) ka[1] = mine; else if (l == 2) ka[2] = mine; else ka[3] = mine;
+          }
+          if (live && (G == 8 || (sub & 1) == 0)) {
+            const int base = ((sub / (G / 2)) & 1) * 12 + ((sub / (G / 4)) & 1) * 6 + ((sub / (G / 8)) & 1) * 3;
+            T* orow = (T*)em.d_off + (g_ / nH) * em.off_ld + ((long)head * 4 + l) * 16;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const int idx = base + k;
+              const int which = idx >> 3, j = idx & 7;
+              if (which) Io<T>::st(orow + j * 2 + (which - 1), part[k] / (which == 1 ? (float)Wl : (float)Hl));
+            }
+          }
+        } else
         if (live && (G == 8 || (sub & 1) == 0)) {
           const int base = ((sub / (G / 2)) & 1) * 12 + ((sub / (G / 4)) & 1) * 6 + ((sub / (G / 8)) & 1) * 3;
 #pragma unroll
@@ -352,6 +378,22 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
       }
     }
 #undef MSDA_LW_POINT
+    if constexpr (EMIT) {
+      // softmax backward over the (q, head) group's 32 points: lane sub < 8 holds d_attw of point `sub` of every level
+      float aw[4], t = 0.f;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        aw[l] = sub < 8 ? ap[l * 8 + sub] : 0.f;
+        t += aw[l] * (sub < 8 ? ka[l] : 0.f);
+      }
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      if (live && sub < 8) {
+        T* lrow = (T*)em.d_logit + (g_ / nH) * em.logit_ld + (long)head * 32 + sub;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) Io<T>::st(lrow + l * 8, aw[l] * (ka[l] - t));
+      }
+    }
   }
 }
 
@@ -857,10 +899,10 @@ extern "C" int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launch
   return GE_OK;
 }
 
-extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
-                           const float* attw, const void* d_out, float* d_value, float* d_loc, float* d_attw, void* workspace,
-                           size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
-  if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || !d_loc || !d_attw) return GE_ERR_BAD_ARG;
+static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
+                         const float* attw, const void* d_out, float* d_value, float* d_loc, float* d_attw, void* workspace,
+                         size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream, const MsdaEmit* em) {
+  if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || (!em && (!d_loc || !d_attw))) return GE_ERR_BAD_ARG;
   if (B < 0 || Nv <= 0 || Nq < 0 || nH <= 0 || P <= 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
@@ -883,6 +925,7 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   const long seg_ints = (long)B * nH * pl.R * pl.ntiles;
   const bool binned = workspace && pl.ok && workspace_bytes >= msda_ws_layout(pl.nbins, seg_ints, pl.max_entries, nullptr, nullptr);
   if (!binned) {
+    if (em) return GE_ERR_UNSUPPORTED;                        // the raw-gradient variant exists on the workspace path only
     if (dtype == GE_F32) MSDA_BWD_P(float, true); else MSDA_BWD_P(bf16_t, true);
     GE_LAUNCH_CHECK();
     return GE_OK;
@@ -893,7 +936,16 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
   hipEvent_t* ev = nullptr;
   { std::lock_guard<std::mutex> lk(g_msda_mu); if (g_msda_timing) ev = evs; }
   msda_mark(ev, 0, s);
-  if ((g_msda_mode & 2) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv)) {
+  if (em) {
+    if (L != 4 || P != 8) return GE_ERR_UNSUPPORTED;
+    const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
+    const bool hm = (g_msda_mode & 8) != 0;
+    g_msda_lw_win_used = false;
+#define MSDA_LWE(TT, HM_) msda_bwd_lw_k<TT, HM_, true><<<lblocks, 256, 0, s>>>((const TT*)value, lv, loc, attw, (const TT*)d_out, nullptr, nullptr, n_groups, Nv, Nq, nH, L, P, *em)
+    if (dtype == GE_F32) { if (hm) MSDA_LWE(float, true); else MSDA_LWE(float, false); }
+    else { if (hm) MSDA_LWE(bf16_t, true); else MSDA_LWE(bf16_t, false); }
+#undef MSDA_LWE
+  } else if ((g_msda_mode & 2) && query_hw && n_qseg > 0 && msda_win_supported(B, Nq, nH, L, P, Nv)) {
     e = msda_bwd_lw_win_launch(value, lv, query_hw, n_qseg, loc, attw, d_out, d_loc, d_attw, B, Nv, Nq, nH, L, P, dtype, (g_msda_mode & 4) != 0, s);
     if (e) return e;
     g_msda_lw_win_used = true;
@@ -941,6 +993,13 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
     for (int i = 0; i < MSDA_NSTAGE; ++i) g_msda_pending.push_back(MsdaStageRec{i, ev[i], ev[i + 1]});
   }
   return GE_OK;
+}
+
+extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
+                           const float* attw, const void* d_out, float* d_value, float* d_loc, float* d_attw, void* workspace,
+                           size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+  return msda_bwd_impl(value, spatial_hw, query_hw, n_qseg, loc, attw, d_out, d_value, d_loc, d_attw, workspace, workspace_bytes, B, Nv, Nq,
+                       nH, L, P, dtype, stream, nullptr);
 }
 
 // ============================================================================ sampling-location / weight preparation
@@ -1103,6 +1162,90 @@ extern "C" int ge_msda_prep_bwd(const float* d_loc, const float* d_attw, const f
   else if (dtype == GE_BF16) { if (P == 8) GE_PREP(bf16_t, 8); else GE_PREP(bf16_t, 4); }
   else return GE_ERR_UNSUPPORTED;
 #undef GE_PREP
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+
+// ============================================================================ fused prepare + sampling ("raw" entry points)
+// d_ref[b, q, l, :] = sum_{h, p} d_loc[b, q, h, l, p, :] from the emitted d_off_raw = d_loc / (W_l, H_l) (the heads of a query are
+// spread over workgroups in the head-major d_loc / d_attw kernel, so the sum is a small pass of its own: one thread per (row, level))
+template <typename T>
+__global__ void __launch_bounds__(256) msda_dref_k(const T* __restrict__ d_off, long off_ld, MsdaLevels lv, float* __restrict__ d_ref, long rows,
+                                                   int nH) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < rows * 4; t += (long)gridDim.x * 256) {
+    const int l = (int)(t & 3);
+    const long row = t >> 2;
+    float sx = 0.f, sy = 0.f;
+    for (int h = 0; h < nH; ++h) {
+      float v[16];
+      ld_run<T, 16>(d_off + row * off_ld + ((long)h * 4 + l) * 16, v);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) { sx += v[2 * p]; sy += v[2 * p + 1]; }
+    }
+    d_ref[t * 2] = sx * (float)lv.W[l];
+    d_ref[t * 2 + 1] = sy * (float)lv.H[l];
+  }
+}
+
+
+// 1 when ge_msda_fwd_raw / ge_msda_bwd_raw run their fused kernels for this geometry under the current kernel-selection mode
+extern "C" int ge_msda_raw_supported(const int* spatial_hw, const int* query_hw, int n_qseg, int B, int Nv, int Nq, int nH, int L, int P) {
+  MsdaLevels lv;
+  if (!spatial_hw || msda_levels(spatial_hw, L, Nv, lv)) return 0;
+  if (L != 4 || P != 8 || !query_hw || n_qseg <= 0 || (g_msda_mode & 5) != 5 || (g_msda_mode & 2)) return 0;
+  if (!msda_win_supported(B, Nq, nH, L, P, Nv)) return 0;
+  MsdaBins bins;
+  msda_bins(lv, L, bins);
+  return msda_plan(bins, B, Nq, nH, L, P).ok ? 1 : 0;
+}
+
+// Forward from the raw projection outputs: off_raw (B*Nq rows, columns (head, level, point, xy)), logit_raw (columns (head, level,
+// point)), reference points (B, Nq, L, 2) with element strides -> out, and loc / attw (fp32, fully written) for the backward.
+extern "C" int ge_msda_fwd_raw(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const void* off_raw, long off_ld,
+                               const void* logit_raw, long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, float* loc,
+                               float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !loc || !attw || !out) return GE_ERR_BAD_ARG;
+  if (dtype != GE_F32 && dtype != GE_BF16) return GE_ERR_UNSUPPORTED;
+  if (!ge_msda_raw_supported(spatial_hw, query_hw, n_qseg, B, Nv, Nq, nH, L, P)) {       // composed: prepare pass, then the sampling kernel
+    int e = ge_msda_prep_fwd(off_raw, off_ld, logit_raw, logit_ld, ref, ref_sb, ref_sq, ref_sl, spatial_hw, loc, attw, B, Nq, nH, L, P, dtype, stream);
+    if (e) return e;
+    return ge_msda_fwd(value, spatial_hw, query_hw, n_qseg, loc, attw, out, B, Nv, Nq, nH, L, P, dtype, stream);
+  }
+  if ((long)B * Nq == 0) return GE_OK;
+  const int es = dtype == GE_BF16 ? 2 : 4;
+  if ((((uintptr_t)off_raw | (uintptr_t)logit_raw) & 15) || off_ld % (16 / es) || logit_ld % (16 / es)) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  MwRaw rw;
+  rw.off = off_raw; rw.off_ld = off_ld; rw.logit = logit_raw; rw.logit_ld = logit_ld;
+  rw.ref = ref; rw.ref_sb = ref_sb; rw.ref_sq = ref_sq; rw.ref_sl = ref_sl; rw.loc_out = loc; rw.attw_out = attw;
+  return msda_fwd_win_raw_launch(value, lv, query_hw, n_qseg, rw, out, B, Nv, Nq, nH, L, P, dtype, ge_stream(stream));
+}
+
+// Backward to the raw projection outputs: d_value (fp32, zero-filled by the caller), d_off_raw / d_logit_raw (storage type, fully
+// written) and, if d_ref != NULL, d_ref (B*Nq, L, 2) fp32.  Needs the workspace of ge_msda_bwd_workspace and a geometry for which
+// ge_msda_raw_supported() is 1.
+extern "C" int ge_msda_bwd_raw(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc, const float* attw,
+                               const void* d_out, float* d_value, void* d_off_raw, long off_ld, void* d_logit_raw, long logit_ld, float* d_ref,
+                               void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+  if (!d_off_raw || !d_logit_raw) return GE_ERR_BAD_ARG;
+  if (!ge_msda_raw_supported(spatial_hw, query_hw, n_qseg, B, Nv, Nq, nH, L, P)) return GE_ERR_UNSUPPORTED;
+  if (!prep_aligned(d_off_raw, off_ld, d_logit_raw, logit_ld, dtype == GE_BF16 ? 2 : 4)) return GE_ERR_BAD_ARG;
+  MsdaEmit em;
+  em.d_off = d_off_raw; em.off_ld = off_ld; em.d_logit = d_logit_raw; em.logit_ld = logit_ld;
+  int e = msda_bwd_impl(value, spatial_hw, query_hw, n_qseg, loc, attw, d_out, d_value, nullptr, nullptr, workspace, workspace_bytes, B, Nv, Nq,
+                        nH, L, P, dtype, stream, &em);
+  if (e || !d_ref) return e;
+  MsdaLevels lv;
+  e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  const long rows = (long)B * Nq;
+  if (rows == 0) return GE_OK;
+  const unsigned blocks = ge_blocks(rows * 4, 256, 1 << 20);
+  if (dtype == GE_F32) msda_dref_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)d_off_raw, off_ld, lv, d_ref, rows, nH);
+  else msda_dref_k<bf16_t><<<blocks, 256, 0, ge_stream(stream)>>>((const bf16_t*)d_off_raw, off_ld, lv, d_ref, rows, nH);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

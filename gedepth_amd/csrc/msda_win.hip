@@ -63,6 +63,45 @@ __device__ __forceinline__ int mw_wave_max(int v) {
   return v;
 }
 
+// RAW = true: the kernel consumes the raw outputs of the `sampling_offsets` / `attention_weights` linears (+ the reference
+// points) instead of ready-made locations / weights, i.e. mmcv's view -> softmax over L*P -> `ref + off / (W_l, H_l)` happens in
+// registers (same arithmetic as msda_prep_fwd_k), and WRITES loc / attw (fp32) for the backward kernels — the separate prepare
+// pass (0.85 + 0.29 ms per step at the KITTI shape) and one read of loc / attw disappear; the stores ride on a VALU-bound kernel.
+template <typename T> __device__ __forceinline__ void mw_ld_pair(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void mw_ld_pair<float>(const float* p, float& a, float& b) { const float2 t = *(const float2*)p; a = t.x; b = t.y; }
+template <> __device__ __forceinline__ void mw_ld_pair<bf16_t>(const bf16_t* p, float& a, float& b) {
+  const uint32_t t = *(const uint32_t*)p; a = __uint_as_float(t << 16); b = __uint_as_float(t & 0xffff0000u);
+}
+// softmax over the L * P = 32 logits of each of this lane group's (query, head) pairs (launcher: L == 4, P == 8); lane sub < 8
+// owns point `sub` of the four levels and stores their weights straight to attw_out — phase A of each level reads them back
+// (its own store, one dword), which keeps 16 registers out of the level loop (the kernel sits at the 3-waves-per-SIMD limit)
+template <typename T>
+__device__ __forceinline__ void mw_softmax(const MwRaw& rw, const int* qbase, const int* qlin, const bool* qok, int head) {
+  constexpr int G = WinGeom<T>::G;
+  const int sub = threadIdx.x % G;
+#pragma unroll
+  for (int i = 0; i < MW_QPG; ++i) {
+    const bool own = sub < 8 && qok[i];
+    const T* lp = (const T*)rw.logit + (long)qlin[i] * rw.logit_ld + head * 32 + sub;
+    float lg[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) lg[l] = own ? Io<T>::ld(lp + l * 8) : -INFINITY;
+    float m = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (!qok[i]) m = 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { lg[l] = own ? expf(lg[l] - m) : 0.f; s += lg[l]; }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (own) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) rw.attw_out[(long)qbase[i] + l * 8 + sub] = lg[l] / s;
+    }
+  }
+}
+
 // Workgroup -> (image, head, tile).  XCD x (= blockIdx % 8) works on a contiguous eighth of the (image, head, tile) range: what
 // it has in flight samples one head of one image (4.2 MB of value rows at the KITTI shape ~ its 4 MB L2).
 struct MwJob { int b, head, seg, ty, tx; bool live; };
@@ -90,10 +129,11 @@ __device__ __forceinline__ MwJob mw_job(const MsdaQGrid& qg, int nH, int B) {
 // Phases A + B for one level.  Each lane with sub < 8 owns sampling point `sub` of the MW_QPG queries of its group:
 // px / py = pixel coordinates, pw = attention weight (0 for a point that samples nothing or a query outside the map).
 // Returns true when the window was staged; box = {xmin, ymin, width, rows}.
-template <typename T>
+template <typename T, bool RAW = false>
 __device__ __forceinline__ bool mw_stage(const T* __restrict__ vl, int Wl, int Hl, int nh64, const float* __restrict__ loc,
                                          const float* __restrict__ attw, const int* qbase, const bool* qok, int l, int P,
-                                         float* px, float* py, float* pw, uint4* win, int* s_box, int box[4]) {
+                                         float* px, float* py, float* pw, uint4* win, int* s_box, int box[4],
+                                         const MwRaw* rw = nullptr, const int* qlin = nullptr, int b = 0, int Nq = 0, int head = 0) {
   constexpr int G = WinGeom<T>::G, NG = WinGeom<T>::NG, CAP = WinGeom<T>::CAP;
   const int sub = threadIdx.x % G;
   int xmin = INT_MAX, ymin = INT_MAX, xmax = -1, ymax = -1;
@@ -103,9 +143,19 @@ __device__ __forceinline__ bool mw_stage(const T* __restrict__ vl, int Wl, int H
     float x = -2.f, y = -2.f, w = 0.f;
     if (sub < 8 && qok[i]) {
       const long o = (long)qbase[i] + l * P + sub;
-      const float2 xy = *(const float2*)(loc + 2 * o);
-      w = attw[o];
-      x = xy.x * (float)Wl - 0.5f; y = xy.y * (float)Hl - 0.5f;
+      if constexpr (RAW) {
+        float ox, oy;
+        mw_ld_pair<T>((const T*)rw->off + (long)qlin[i] * rw->off_ld + ((head * 4 + l) * 8 + sub) * 2, ox, oy);
+        const float* rp = rw->ref + (long)b * rw->ref_sb + (long)(qlin[i] - b * Nq) * rw->ref_sq + (long)l * rw->ref_sl;
+        const float lx = rp[0] + ox / (float)Wl, ly = rp[1] + oy / (float)Hl;      // msda_prep_fwd_k's arithmetic
+        w = rw->attw_out[o];                                                       // written by mw_softmax (this lane)
+        *(float2*)(rw->loc_out + 2 * o) = make_float2(lx, ly);
+        x = lx * (float)Wl - 0.5f; y = ly * (float)Hl - 0.5f;
+      } else {
+        const float2 xy = *(const float2*)(loc + 2 * o);
+        w = attw[o];
+        x = xy.x * (float)Wl - 0.5f; y = xy.y * (float)Hl - 0.5f;
+      }
     }
     const bool in = y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl;     // NaN-safe: a NaN location samples nothing
     if (!in) { x = -2.f; y = -2.f; w = 0.f; }
@@ -191,7 +241,8 @@ template <> struct MwAcc<float> {
 
 // Shared prologue: the MW_QPG queries of this lane group.  Local query index g + NG * i inside the TQH x TQW tile.
 template <typename T>
-__device__ __forceinline__ void mw_queries(const MsdaQGrid& qg, const MwJob& job, int Nq, int nH, int LP, int* qbase, int* qrow, bool* qok) {
+__device__ __forceinline__ void mw_queries(const MsdaQGrid& qg, const MwJob& job, int Nq, int nH, int LP, int* qbase, int* qrow, bool* qok,
+                                           int* qlin = nullptr) {
   constexpr int G = WinGeom<T>::G, NG = WinGeom<T>::NG, TQW = WinGeom<T>::TQW, TQH = WinGeom<T>::TQH;
   const int g = threadIdx.x / G;
   const int Hs = qg.H[job.seg], Ws = qg.W[job.seg];
@@ -201,6 +252,7 @@ __device__ __forceinline__ void mw_queries(const MsdaQGrid& qg, const MwJob& job
     const int y = job.ty * TQH + qi / TQW, x = job.tx * TQW + qi % TQW;
     qok[i] = job.live && y < Hs && x < Ws;
     const long q = qg.start[job.seg] + (long)(qok[i] ? y : 0) * Ws + (qok[i] ? x : 0);
+    if (qlin) qlin[i] = (int)((long)job.b * Nq + q);
     qrow[i] = (int)(((long)job.b * Nq + q) * nH + job.head);    // (b, q, head) index: * 64 = output / gradient row
     qbase[i] = qrow[i] * LP;                                     // * 2 = loc offset, * 1 = attw offset (launcher: < 2^31)
   }
@@ -209,19 +261,20 @@ __device__ __forceinline__ void mw_queries(const MsdaQGrid& qg, const MwJob& job
 // PRE = true: the lane that owns a sampling point also does its tap arithmetic once (window row index with the +1 column /
 // +1 row flags packed into bits 30 / 31, the four final weights) and the 8 lanes of the group fetch 5 values per point by
 // ds_bpermute, instead of every lane redoing the floor / clamp / mask arithmetic from (x, y, weight): ~35 VALU less per point.
-template <typename T, bool PRE>
+template <typename T, bool PRE, bool RAW = false>
 __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ value, MsdaLevels lv, MsdaQGrid qg,
                                                       const float* __restrict__ loc, const float* __restrict__ attw,
-                                                      T* __restrict__ out, int B, int Nv, int Nq, int nH, int L, int P) {
+                                                      T* __restrict__ out, int B, int Nv, int Nq, int nH, int L, int P, MwRaw rw = MwRaw()) {
   constexpr int CPL = WinGeom<T>::CPL, G = WinGeom<T>::G;
   __shared__ uint4 win[MW_BYTES / 16];
   __shared__ int s_box[4];
   const int sub = threadIdx.x % G;
   const MwJob job = mw_job(qg, nH, B);
   const int nh64 = nH * 64;
-  int qbase[MW_QPG], qrow[MW_QPG];
+  int qbase[MW_QPG], qrow[MW_QPG], qlin[MW_QPG];
   bool qok[MW_QPG];
-  mw_queries<T>(qg, job, Nq, nH, L * P, qbase, qrow, qok);
+  mw_queries<T>(qg, job, Nq, nH, L * P, qbase, qrow, qok, RAW ? qlin : nullptr);
+  if constexpr (RAW) mw_softmax<T>(rw, qbase, qlin, qok, job.head);
   float acc[MW_QPG][CPL];
 #pragma unroll
   for (int i = 0; i < MW_QPG; ++i)
@@ -233,7 +286,8 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
     const T* vl = vb + (long)lv.start[l] * nH * 64;
     float px[MW_QPG], py[MW_QPG], pw[MW_QPG];
     int box[4];
-    const bool staged = mw_stage<T>(vl, Wl, Hl, nh64, loc, attw, qbase, qok, l, P, px, py, pw, win, s_box, box);
+    const bool staged = mw_stage<T, RAW>(vl, Wl, Hl, nh64, loc, attw, qbase, qok, l, P, px, py, pw, win, s_box, box, &rw, qlin, job.b, Nq,
+                                         job.head);
     if (box[3] == 0) continue;                                  // nothing in this tile samples level l (uniform)
     const int x0w = box[0], y0w = box[1], bw = box[2];
     const uint4* gsrc = (const uint4*)(vl + sub * CPL);
@@ -494,6 +548,23 @@ int msda_fwd_win_launch(const void* value, const MsdaLevels& lv, const int* quer
   if (f32) { if (pre) MW_FWD(float, true); else MW_FWD(float, false); }
   else { if (pre) MW_FWD(bf16_t, true); else MW_FWD(bf16_t, false); }
 #undef MW_FWD
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+// Fused prepare + forward (RAW): owner-lane kernel only (PRE), L == 4 and P == 8 (the HAHI configuration; checked by the caller).
+int msda_fwd_win_raw_launch(const void* value, const MsdaLevels& lv, const int* query_hw, int n_qseg, const MwRaw& rw, void* out, int B,
+                            int Nv, int Nq, int nH, int L, int P, int dtype, hipStream_t s) {
+  MsdaQGrid qg;
+  const bool f32 = dtype == GE_F32;
+  int e = mw_qgrid(query_hw, n_qseg, Nq, f32 ? WinGeom<float>::TQH : WinGeom<bf16_t>::TQH, 16, qg);
+  if (e) return e;
+  const long total = (long)B * qg.tile_first[qg.nseg] * nH;
+  if (total <= 0) return GE_OK;
+  if (total > (1L << 30)) return GE_ERR_UNSUPPORTED;
+  const unsigned blocks = msda_grid(total, 1);
+  if (f32) msda_fwd_win_k<float, true, true><<<blocks, 256, 0, s>>>((const float*)value, lv, qg, nullptr, nullptr, (float*)out, B, Nv, Nq, nH, L, P, rw);
+  else msda_fwd_win_k<bf16_t, true, true><<<blocks, 256, 0, s>>>((const bf16_t*)value, lv, qg, nullptr, nullptr, (bf16_t*)out, B, Nv, Nq, nH, L, P, rw);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ....kernels import concat_tokens_map, ms_deform_attn, msda_prepare, tokens_from_map
+from ....kernels import concat_tokens_map, ms_deform_attn_raw, tokens_from_map
 from ....mmrt import bricks
 from ....mmrt.bricks import BaseModule, ConvModule, build_positional_encoding, xavier_init
 from ..builder import ATTENTION, NECKS
@@ -54,7 +54,7 @@ class MultiScaleDeformableAttention(BaseModule):
         """query (B,Nq,C) with the positional embedding already added, value (B,Nv,C) -> output_proj(sampled) (B,Nq,C).
 
         The two query linears run as ONE GEMM on concatenated weights (their input is the same 0.4-0.8 GB tensor), and
-        view / softmax / normaliser / reference-point arithmetic is one HIP pass (kernels.msda_prepare)."""
+        view / softmax / normaliser / reference-point arithmetic is folded into the sampling kernel (kernels.ms_deform_attn_raw)."""
         bs, num_query, _ = query.shape
         num_value = value.shape[1]
         if torch.is_tensor(spatial_shapes):
@@ -70,9 +70,11 @@ class MultiScaleDeformableAttention(BaseModule):
         w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
         b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
         raw = bricks.linear_tokens(query, w, b)               # (B, Nq, nH*L*P*2 + nH*L*P)
-        # sampling locations / weights are fp32 (pixel coordinates up to ~1000 need > 8 mantissa bits)
-        loc, weights = msda_prepare(raw, reference_points.expand(bs, num_query, L, 2), spatial_shapes, nH, L, P)
-        out = ms_deform_attn(value, spatial_shapes, loc, weights, query_shapes)
+        # view / softmax / normaliser / reference-point arithmetic happen inside the sampling kernel (fp32 locations and weights:
+        # pixel coordinates up to ~1000 need > 8 mantissa bits); its backward returns the gradient of `raw` directly
+        if raw.dtype != value.dtype:
+            raw = raw.to(value.dtype)
+        out = ms_deform_attn_raw(value, raw, reference_points.expand(bs, num_query, L, 2), spatial_shapes, query_shapes, nH, L, P)
         return self.output_proj(out)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,

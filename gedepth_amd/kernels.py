@@ -279,6 +279,89 @@ def msda_prepare(raw, reference_points, spatial_shapes, num_heads, num_levels, n
     return _MSDAPrep.apply(raw, reference_points, spatial_shapes, num_heads, num_levels, num_points)
 
 
+class _MSDeformAttnRaw(torch.autograd.Function):
+    """prepare + sampling in one kernel each way (ge_msda_fwd_raw / ge_msda_bwd_raw)."""
+
+    @staticmethod
+    def forward(ctx, value, raw, ref, spatial_shapes, query_shapes, nH, L, P):
+        value, raw = _c(value), _c(raw)
+        B, Nv, _, D = value.shape
+        _, Nq, ld = raw.shape
+        n_off, n_log = nH * L * P * 2, nH * L * P
+        assert D == 64 and ld == n_off + n_log and raw.dtype == value.dtype
+        ref = ref.to(_f32)
+        assert ref.is_cuda and tuple(ref.shape) == (B, Nq, L, 2)
+        if ref.stride(3) != 1:
+            ref = ref.contiguous()
+        arr, _ = _levels(spatial_shapes)
+        qarr, nq = _query_grid(query_shapes, Nq)
+        loc = torch.empty(B, Nq, nH, L, P, 2, device=raw.device, dtype=_f32)
+        attw = torch.empty(B, Nq, nH, L, P, device=raw.device, dtype=_f32)
+        out = torch.empty(B, Nq, nH * D, device=value.device, dtype=value.dtype)
+        es = _es(raw)
+        base = hip.ptr(raw, name='raw')
+        nbytes = value.numel() * _es(value) + raw.numel() * es + (loc.numel() + attw.numel()) * 4 + out.numel() * _es(out)
+        PROFILER.run(f'msda_fwd_raw[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(hip.lib().ge_msda_fwd_raw(
+            hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), qarr, nq, base, ld, base + n_off * es, ld, ref.data_ptr(),
+            ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(loc), hip.ptr(attw), hip.ptr(out), B, Nv, Nq, nH, L, P,
+            hip.dtype_code(value), hip.stream()), 'ge_msda_fwd_raw'))
+        ctx.save_for_backward(value, loc, attw)
+        ctx.meta = (tuple(tuple(int(v) for v in hw) for hw in spatial_shapes), tuple(tuple(int(v) for v in hw) for hw in query_shapes),
+                    nH, L, P, ld, raw.dtype)
+        ctx.last_loc = loc
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        value, loc, attw = ctx.saved_tensors
+        shapes, qshapes, nH, L, P, ld, dtype = ctx.meta
+        B, Nv, _, D = value.shape
+        Nq = loc.shape[1]
+        d_out = _c(d_out.to(value.dtype))
+        arr, _ = _levels(shapes)
+        qarr, nq = _query_grid(qshapes, Nq)
+        shapes_p = ctypes.cast(arr, ctypes.c_void_p)
+        lib = hip.lib()
+        d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
+        d_raw = torch.empty(B, Nq, ld, device=value.device, dtype=dtype)
+        d_ref = torch.empty(B, Nq, L, 2, device=value.device, dtype=_f32) if ctx.needs_input_grad[2] else None
+        ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
+        ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8)
+        es = _es(d_raw)
+        base = hip.ptr(d_raw)
+        n_off = nH * L * P * 2
+        if PROFILER.on:
+            lw_b = value.numel() * _es(value) + (loc.numel() + attw.numel()) * 4 + d_raw.numel() * es + d_out.numel() * _es(d_out)
+            la_b = (loc.numel() + attw.numel()) * 4
+            PROFILER.add_stage_bytes((lw_b, la_b, 0, la_b, d_out.numel() * _es(d_out) + d_value.numel() * 4))
+        nbytes = (value.numel() * _es(value) + (loc.numel() + attw.numel()) * 4 + d_raw.numel() * es + d_out.numel() * _es(d_out)
+                  + d_value.numel() * 4)
+        PROFILER.run(f'msda_bwd_raw[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(lib.ge_msda_bwd_raw(
+            hip.ptr(value), shapes_p, qarr, nq, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out), hip.ptr(d_value), base, ld, base + n_off * es, ld,
+            hip.ptr(d_ref), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()), 'ge_msda_bwd_raw'))
+        return d_value.to(value.dtype), d_raw, d_ref, None, None, None, None, None
+
+
+def ms_deform_attn_raw(value, raw, reference_points, spatial_shapes, query_shapes, num_heads, num_levels, num_points):
+    """mmcv MultiScaleDeformableAttention's sampling half from the RAW projection outputs:
+    ``ms_deform_attn(value, shapes, *msda_prepare(raw, reference_points, ...), query_shapes)`` — one kernel each way when the
+    geometry allows (4 levels, 8 points, a query grid, workspace backward: ``ge_msda_raw_supported``), else exactly that composition.
+    value (B,Nv,nH,64), raw (B,Nq,[nH*L*P*2 offsets | nH*L*P logits]) same dtype, reference points (B,Nq,L,2) -> (B,Nq,nH*64)."""
+    B, Nv = value.shape[:2]
+    Nq = raw.shape[1]
+    fused = (query_shapes is not None and MSDA_BINNED_BACKWARD and value.is_cuda and raw.dtype == value.dtype
+             and value.dtype in (_f32, torch.bfloat16))
+    if fused:
+        arr, _ = _levels(spatial_shapes)
+        qarr, nq = _query_grid(query_shapes, Nq)
+        fused = bool(hip.lib().ge_msda_raw_supported(ctypes.cast(arr, ctypes.c_void_p), qarr, nq, B, Nv, Nq, num_heads, num_levels, num_points))
+        fused = fused and int(hip.lib().ge_msda_bwd_workspace(ctypes.cast(arr, ctypes.c_void_p), B, Nv, Nq, num_heads, num_levels, num_points)) > 0
+    if not fused:
+        loc, attw = msda_prepare(raw, reference_points, spatial_shapes, num_heads, num_levels, num_points)
+        return ms_deform_attn(value, spatial_shapes, loc, attw, query_shapes)
+    return _MSDeformAttnRaw.apply(value, raw, reference_points, spatial_shapes, query_shapes, int(num_heads), int(num_levels), int(num_points))
+
+
 # ---------------------------------------------------------------------------- channels-last helpers
 _CL = torch.channels_last
 

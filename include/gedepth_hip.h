@@ -146,6 +146,25 @@ int ge_msda_prep_fwd(const void* off_raw, long off_ld, const void* logit_raw, lo
 int ge_msda_prep_bwd(const float* d_loc, const float* d_attw, const float* attw, const int* spatial_hw, void* d_off_raw,
                      long off_ld, void* d_logit_raw, long logit_ld, float* d_ref, int B, int Nq, int nH, int L, int P,
                      int dtype, void* stream);
+
+/* Fused prepare + sampling ("raw" entry points, round 3): the deformable attention taken from the RAW outputs of the
+ * `sampling_offsets` / `attention_weights` linears — mmcv MultiScaleDeformableAttention.forward's view -> softmax over L*P ->
+ * `reference_points + offsets / (W_l, H_l)` -> ms_deform_attn in ONE kernel (replaces ge_msda_prep_fwd + ge_msda_fwd; reference
+ * call sites depth/models/necks/hahi.py:279-289,316-325), and its backward straight to the gradient of those raw outputs
+ * (replaces ge_msda_bwd + ge_msda_prep_bwd).
+ *   off_raw   (B*Nq rows of off_ld elements; columns (head, level, point, xy)), logit_raw (rows of logit_ld; columns (head,
+ *             level, point)), storage type `dtype`; ref (B, Nq, L, 2) f32 with ELEMENT strides ref_sb / ref_sq / ref_sl (0 = broadcast)
+ *   loc, attw (B,Nq,nH,L,P[,2]) f32: WRITTEN by the forward, read by the backward (what ge_msda_prep_fwd would have produced)
+ *   d_off_raw / d_logit_raw: same layout and type as off_raw / logit_raw, fully written; d_ref (B*Nq, L, 2) f32 or NULL.
+ * ge_msda_raw_supported() = 1 when the fused kernels apply (L == 4, P == 8, a query grid, default kernel-selection mode);
+ * ge_msda_fwd_raw otherwise runs the two-pass composition itself, ge_msda_bwd_raw returns GE_ERR_UNSUPPORTED. */
+int ge_msda_raw_supported(const int* spatial_hw, const int* query_hw, int n_qseg, int B, int Nv, int Nq, int nH, int L, int P);
+int ge_msda_fwd_raw(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const void* off_raw, long off_ld,
+                    const void* logit_raw, long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, float* loc,
+                    float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+int ge_msda_bwd_raw(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc, const float* attw,
+                    const void* d_out, float* d_value, void* d_off_raw, long off_ld, void* d_logit_raw, long logit_ld, float* d_ref,
+                    void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 int ge_tokens_from_map(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
                        float p_drop, unsigned long long seed, int dtype, void* stream);
 int ge_map_from_tokens(const void* tok, long tok_bs, const void* res, long res_bs, void* map, long map_bs, int B, int C,

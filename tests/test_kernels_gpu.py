@@ -4,6 +4,8 @@ import json
 import os
 
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -452,6 +454,72 @@ def test_msda_drain_many_records_per_tile(dev, mode):
         msda_mode(old)
     assert ('msda_drain_mfma_k' if mode & 16 else 'msda_drain_k') in stages, stages
     close_scaled(vg.grad.float(), vc.grad, rel=1e-2, what=f'bf16 d value, mode {mode}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', ['self', 'cross'])
+def test_msda_raw_fused_prepare_and_sampling(dev, dtype, case):
+    """kernels.ms_deform_attn_raw (ge_msda_fwd_raw / ge_msda_bwd_raw: view -> softmax -> normaliser -> reference points -> sampling
+    in one kernel, and its backward straight to the raw projection gradient) against (1) mmcv's arithmetic written out in torch on
+    the CPU with the oracle's sampling core, differentiated by autograd (fp32), and (2) the two-pass composition msda_prepare +
+    ms_deform_attn on the GPU (both dtypes): out, d_value, d_raw (offsets and logits), d_ref.  'self': queries = the four levels
+    (ragged tiles), reference = pixel centres; 'cross': one 2x query map, reference points requiring a gradient."""
+    from gedepth_amd import hip
+    from gedepth_amd.kernels import ms_deform_attn_raw, msda_mode
+    shapes = [(22, 35), (11, 18), (6, 9), (3, 5)]
+    qshapes = shapes if case == 'self' else [(44, 70)]
+    B, nH, L, P = 2, 8, 4, 8
+    nv = sum(h * w for h, w in shapes)
+    nq = sum(h * w for h, w in qshapes)
+    g = gen(23)
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    value = torch.randn(B, nv, nH, 64, generator=g).to(td)
+    raw = torch.cat((torch.randn(B, nq, nH * L * P * 2, generator=g) * 2.5, torch.randn(B, nq, nH * L * P, generator=g)), -1).to(td)
+    refs = []
+    for h, w in qshapes:
+        gy, gx = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(B, nq, L, 2).contiguous()
+    if case == 'cross':
+        ref = (ref + 0.02 * torch.randn(B, nq, L, 2, generator=g)).clamp(0.01, 0.99)
+    go = torch.randn(B, nq, nH * 64, generator=g).to(td)
+
+    def run(mode):
+        old = msda_mode(mode)
+        try:
+            v, r, rf = value.to(dev).requires_grad_(True), raw.to(dev).requires_grad_(True), ref.to(dev).requires_grad_(True)
+            out = ms_deform_attn_raw(v, r, rf, shapes, qshapes, nH, L, P)
+            out.backward(go.to(dev))
+            return [t.float().cpu() for t in (out, v.grad, r.grad, rf.grad)]
+        finally:
+            msda_mode(old)
+    arr = (ctypes.c_int * 8)(*[x for hw in shapes for x in hw])
+    qa = (ctypes.c_int * (2 * len(qshapes)))(*[x for hw in qshapes for x in hw])
+    sup = hip.lib().ge_msda_raw_supported(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(qa, ctypes.c_void_p), len(qshapes), B, nv, nq, nH, L, P)
+    assert sup == 1                                            # the fused kernels are what `run(61)` exercises
+    fused = run(61)
+    composed = run(60)                                         # mode without the window forward: prepare pass + streaming kernels
+    n_off = nH * L * P * 2
+    names = ('out', 'd value', 'd raw', 'd ref')
+    for a, b, n in zip(fused, composed, names):
+        if dtype == 'f32':
+            close_scaled(a, b, rel=3e-5, what=f'fused vs composed: {n}')
+        else:                                                   # bf16: outputs / d_value / d_raw are rounded to bf16 once on either path
+            close_scaled(a, b, rel=1e-2, what=f'fused vs composed (bf16): {n}')
+    if dtype == 'f32':
+        vc, rc, fc = value.clone().requires_grad_(True), raw.clone().requires_grad_(True), ref.clone().requires_grad_(True)
+        off = rc[..., :n_off].view(B, nq, nH, L, P, 2)
+        norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+        loc = fc[:, :, None, :, None, :] + off / norm
+        aw = rc[..., n_off:].view(B, nq, nH, L * P).softmax(-1).view(B, nq, nH, L, P)
+        o = O.msda_core(vc, shapes, loc, aw)
+        o.backward(go)
+        close(fused[0], o, what='out vs oracle')
+        close_scaled(fused[1], vc.grad, what='d value vs oracle')
+        close_scaled(fused[2][..., n_off:], rc.grad[..., n_off:], rel=2e-4, what='d logits vs oracle')
+        close_scaled(fused[2][..., :n_off], rc.grad[..., :n_off], rel=2e-4, what='d offsets vs oracle')
+        close_scaled(fused[3], fc.grad, rel=2e-4, what='d ref vs oracle')
 
 
 def test_msda_module_golden(dev, golden):
