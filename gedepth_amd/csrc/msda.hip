@@ -342,14 +342,18 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
             const float mine = r3 == 0 ? q0 : r3 == 1 ? q1 : q2;
             if (l == 0) ka[0] = mine; else if (l == 1) ka[1] = mine; else if (l == 2) ka[2] = mine; else ka[3] = mine;
           }
-          if (live && (G == 8 || (sub & 1) == 0)) {
-            const int base = ((sub / (G / 2)) & 1) * 12 + ((sub / (G / 4)) & 1) * 6 + ((sub / (G / 8)) & 1) * 3;
-            T* orow = (T*)em.d_off + (g_ / nH) * em.off_ld + ((long)head * 4 + l) * 16;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const int idx = base + k;
-              const int which = idx >> 3, j = idx & 7;
-              if (which) Io<T>::st(orow + j * 2 + (which - 1), part[k] / (which == 1 ? (float)Wl : (float)Hl));
+          {   // the 16 d_loc sums of the level (idx 8 + j: d/dx of point j, idx 16 + j: d/dy): lane j collects its point's pair and
+              // the group stores the level's 16 offsets gradients as ONE contiguous run (32 bytes in bf16) instead of 16 two-byte stores
+            const int j = sub < 8 ? sub : 0;
+            const int sx = ((8 + j) / 3) * (G / 8), sy = ((16 + j) / 3) * (G / 8);
+            const float x0 = __shfl(part[0], sx, G), x1 = __shfl(part[1], sx, G), x2 = __shfl(part[2], sx, G);
+            const float y0 = __shfl(part[0], sy, G), y1 = __shfl(part[1], sy, G), y2 = __shfl(part[2], sy, G);
+            const int rx = (8 + j) % 3, ry = (16 + j) % 3;
+            const float gx = (rx == 0 ? x0 : rx == 1 ? x1 : x2) / (float)Wl, gy = (ry == 0 ? y0 : ry == 1 ? y1 : y2) / (float)Hl;
+            if (live && sub < 8) {
+              T* orow = (T*)em.d_off + (g_ / nH) * em.off_ld + ((long)head * 4 + l) * 16 + sub * 2;
+              if constexpr (sizeof(T) == 2) *(uint32_t*)orow = (uint32_t)f2bf(gx) | ((uint32_t)f2bf(gy) << 16);
+              else *(float2*)orow = make_float2(gx, gy);
             }
           }
         } else

@@ -72,11 +72,14 @@ template <> __device__ __forceinline__ void mw_ld_pair<float>(const float* p, fl
 template <> __device__ __forceinline__ void mw_ld_pair<bf16_t>(const bf16_t* p, float& a, float& b) {
   const uint32_t t = *(const uint32_t*)p; a = __uint_as_float(t << 16); b = __uint_as_float(t & 0xffff0000u);
 }
-// softmax over the L * P = 32 logits of each of this lane group's (query, head) pairs (launcher: L == 4, P == 8); lane sub < 8
-// owns point `sub` of the four levels and stores their weights straight to attw_out — phase A of each level reads them back
-// (its own store, one dword), which keeps 16 registers out of the level loop (the kernel sits at the 3-waves-per-SIMD limit)
+// Prepare pre-pass of the RAW kernel (launcher: L == 4, P == 8): softmax over the 32 logits of each of this lane group's (query,
+// head) pairs and `ref + off / (W_l, H_l)` for its 32 points, written to loc_out / attw_out at once — lane sub < 8 owns point `sub` of
+// the four levels, so a (query, head) leaves as four 64-byte + four 32-byte stores issued back to back (256 + 128 contiguous bytes:
+// complete lines for the L2 to write back; storing level by level inside the level loop left partial lines behind, the fill-pass
+// lesson of msda.hip).  Phase A of each level then reads its points back like the plain kernel does (L2 hits).
 template <typename T>
-__device__ __forceinline__ void mw_softmax(const MwRaw& rw, const int* qbase, const int* qlin, const bool* qok, int head) {
+__device__ __forceinline__ void mw_prepare(const MwRaw& rw, const MsdaLevels& lv, const int* qbase, const int* qlin, const bool* qok, int b,
+                                           int Nq, int head) {
   constexpr int G = WinGeom<T>::G;
   const int sub = threadIdx.x % G;
 #pragma unroll
@@ -96,8 +99,20 @@ __device__ __forceinline__ void mw_softmax(const MwRaw& rw, const int* qbase, co
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (own) {
+      const T* op = (const T*)rw.off + (long)qlin[i] * rw.off_ld + (head * 32 + sub) * 2;
+      const float* rp = rw.ref + (long)b * rw.ref_sb + (long)(qlin[i] - b * Nq) * rw.ref_sq;
+      float2 xy[4];
 #pragma unroll
-      for (int l = 0; l < 4; ++l) rw.attw_out[(long)qbase[i] + l * 8 + sub] = lg[l] / s;
+      for (int l = 0; l < 4; ++l) {
+        float ox, oy;
+        mw_ld_pair<T>(op + l * 16, ox, oy);
+        xy[l] = make_float2(rp[l * rw.ref_sl] + ox / (float)lv.W[l], rp[l * rw.ref_sl + 1] + oy / (float)lv.H[l]);   // msda_prep_fwd_k's arithmetic
+      }
+      const long o = (long)qbase[i] + sub;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) *(float2*)(rw.loc_out + 2 * (o + l * 8)) = xy[l];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) rw.attw_out[o + l * 8] = lg[l] / s;
     }
   }
 }
@@ -144,13 +159,9 @@ __device__ __forceinline__ bool mw_stage(const T* __restrict__ vl, int Wl, int H
     if (sub < 8 && qok[i]) {
       const long o = (long)qbase[i] + l * P + sub;
       if constexpr (RAW) {
-        float ox, oy;
-        mw_ld_pair<T>((const T*)rw->off + (long)qlin[i] * rw->off_ld + ((head * 4 + l) * 8 + sub) * 2, ox, oy);
-        const float* rp = rw->ref + (long)b * rw->ref_sb + (long)(qlin[i] - b * Nq) * rw->ref_sq + (long)l * rw->ref_sl;
-        const float lx = rp[0] + ox / (float)Wl, ly = rp[1] + oy / (float)Hl;      // msda_prep_fwd_k's arithmetic
-        w = rw->attw_out[o];                                                       // written by mw_softmax (this lane)
-        *(float2*)(rw->loc_out + 2 * o) = make_float2(lx, ly);
-        x = lx * (float)Wl - 0.5f; y = ly * (float)Hl - 0.5f;
+        const float2 xy = *(const float2*)(rw->loc_out + 2 * o);      // written by mw_prepare (this lane)
+        w = rw->attw_out[o];
+        x = xy.x * (float)Wl - 0.5f; y = xy.y * (float)Hl - 0.5f;
       } else {
         const float2 xy = *(const float2*)(loc + 2 * o);
         w = attw[o];
@@ -274,7 +285,7 @@ __global__ void __launch_bounds__(256) msda_fwd_win_k(const T* __restrict__ valu
   int qbase[MW_QPG], qrow[MW_QPG], qlin[MW_QPG];
   bool qok[MW_QPG];
   mw_queries<T>(qg, job, Nq, nH, L * P, qbase, qrow, qok, RAW ? qlin : nullptr);
-  if constexpr (RAW) mw_softmax<T>(rw, qbase, qlin, qok, job.head);
+  if constexpr (RAW) mw_prepare<T>(rw, lv, qbase, qlin, qok, job.b, Nq, job.head);
   float acc[MW_QPG][CPL];
 #pragma unroll
   for (int i = 0; i < MW_QPG; ++i)
