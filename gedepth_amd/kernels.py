@@ -671,6 +671,32 @@ def colsum(x):
     return out
 
 
+def bias_gelu_fwd(y0, bias):
+    """gelu(y0 + bias) over a (rows, C) matrix (the bias-free output of the FFN's first GEMM); bias fp32 (C) or None."""
+    C = y0.shape[-1]
+    R = y0.numel() // C
+    out = torch.empty_like(y0)
+    PROFILER.run(f'bias_gelu_fwd[{R}x{C} {_tag(y0)}]', 2 * y0.numel() * _es(y0), lambda: hip.check(hip.lib().ge_bias_gelu_fwd(
+        hip.ptr(y0, name='y0'), hip.ptr(bias, _f32), hip.ptr(out), R, C, hip.dtype_code(y0), hip.stream()), 'ge_bias_gelu_fwd'))
+    return out
+
+
+def bias_gelu_bwd(dg, y0, bias):
+    """-> (dy = dg * gelu'(y0 + bias) in the storage type, d_bias fp32 (C) = column sums of dy), one sweep."""
+    C = y0.shape[-1]
+    R = y0.numel() // C
+    dy = torch.empty_like(y0)
+    db = torch.empty(C, device=y0.device, dtype=_f32)
+    key = (y0.device, C, torch.cuda.current_stream(y0.device).cuda_stream)
+    ws = _COLSUM_WS.get(key)
+    if ws is None:
+        ws = _COLSUM_WS[key] = torch.empty(int(hip.lib().ge_nhwc_workspace(C, 1)), device=y0.device, dtype=torch.uint8)
+    PROFILER.run(f'bias_gelu_bwd[{R}x{C} {_tag(y0)}]', 3 * y0.numel() * _es(y0), lambda: hip.check(hip.lib().ge_bias_gelu_bwd(
+        hip.ptr(dg, name='dg'), hip.ptr(y0), hip.ptr(bias, _f32), hip.ptr(dy), hip.ptr(db), hip.ptr(ws), R, C, hip.dtype_code(y0),
+        hip.stream()), 'ge_bias_gelu_bwd'))
+    return dy, db
+
+
 def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     """LayerNorm over the last dim; x f32/bf16, statistics f32, output ``out_dtype`` (default: x.dtype)."""
     return _LayerNorm.apply(x, weight, bias, float(eps), out_dtype or x.dtype)

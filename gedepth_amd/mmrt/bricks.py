@@ -105,7 +105,9 @@ class ModuleList(BaseModule, nn.ModuleList):
 # ----------------------------------------------------------------------------------- layers
 def _split_k(tokens):
     """Number of K-chunks for the weight gradient of a Linear over ``tokens`` rows (0: leave it to the library)."""
-    if tokens < 32768:
+    # measured (scratch/wgrad_splitk2.py, MI355X): 12320 tokens x (1536 x 384) 70 us plain -> 44 us with 8 - 28 chunks, (384 x 384) 46 -> 29;
+    # 3080 tokens: the plain GEMM is fastest (27 - 39 us); >= 49280 tokens: 2 - 3x from 32 - 44 chunks
+    if tokens < 8192:
         return 0
     for s in range(64, 3, -1):                    # the largest divisor <= 64 that leaves chunks of >= 1024 tokens
         if tokens % s == 0 and tokens // s >= 1024:
@@ -156,6 +158,62 @@ class _LinearTokens(torch.autograd.Function):
                 else:                                                                 # e.g. the 2-wide reference-point Linear of HAHI
                     db = dy2.sum(0, dtype=torch.float32).to(b_dtype)
         return dx, dw, db, None
+
+
+class _LinearBiasGelu(torch.autograd.Function):
+    """``gelu(F.linear(x, W, b))`` (the first half of mmcv's FFN, exact erf GELU) as: bias-free library GEMM -> one HIP pass
+    ``gelu(y0 + b)`` (csrc/nhwc.hip ge_bias_gelu_fwd); backward: one HIP pass that recomputes the pre-activation, multiplies by
+    GELU' and accumulates the bias gradient (ge_bias_gelu_bwd: no separate column-sum read of d_y), then the library input-gradient
+    GEMM and the split-K weight gradient of ``_LinearTokens``.  Saves x, W and y0 (what autograd saved before: x, W, y)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, splits):
+        from .. import kernels
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
+        with torch.autocast('cuda', enabled=False):
+            from .optim import lowp
+            xc, wc = x.to(dt), lowp(weight, dt)
+            y0 = F.linear(xc, wc, None)
+            b32 = bias.detach().float().contiguous()
+            g = kernels.bias_gelu_fwd(y0, b32)
+        ctx.save_for_backward(xc, wc, y0, b32)
+        ctx.meta = (splits, x.dtype, weight.dtype, bias.dtype)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        from .. import kernels
+        xc, wc, y0, b32 = ctx.saved_tensors
+        splits, x_dtype, w_dtype, b_dtype = ctx.meta
+        K = xc.numel() // xc.shape[-1]
+        with torch.autocast('cuda', enabled=False):
+            dg2 = dg.to(wc.dtype).reshape(K, -1)
+            if not dg2.is_contiguous():
+                dg2 = dg2.contiguous()
+            dy2, db = kernels.bias_gelu_bwd(dg2, y0.reshape(K, -1), b32)
+            x2 = xc.reshape(K, -1)
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                dx = (dy2 @ wc).reshape(xc.shape).to(x_dtype)
+            if ctx.needs_input_grad[1]:
+                if splits:
+                    M, N = dy2.shape[1], x2.shape[1]
+                    part = torch.bmm(dy2.view(splits, K // splits, M).transpose(1, 2), x2.view(splits, K // splits, N))
+                    dw = part.sum(0, dtype=torch.float32).to(w_dtype)
+                else:
+                    dw = (dy2.t() @ x2).to(w_dtype)
+        return dx, dw, (db.to(b_dtype) if ctx.needs_input_grad[2] else None), None
+
+
+def linear_bias_gelu(x, weight, bias):
+    """``F.gelu(F.linear(x, weight, bias))`` (exact GELU) with the bias + GELU epilogue kernels; eager composition off the GPU /
+    outside training / for channel counts that are not whole 16-byte vectors."""
+    C = weight.shape[0]
+    ok = (x.is_cuda and torch.is_grad_enabled() and weight.requires_grad and bias is not None and x.dim() >= 2 and x.numel() > 0
+          and x.dtype in (torch.float32, torch.bfloat16) and C % 8 == 0)
+    if not ok:
+        return F.gelu(linear_tokens(x, weight, bias))
+    return _LinearBiasGelu.apply(x, weight, bias, _split_k(x.numel() // x.shape[-1]))
 
 
 def linear_tokens(x, weight, bias=None):
@@ -422,8 +480,20 @@ class FFN(BaseModule):
         self.dropout_layer = build_dropout(dropout_layer) if dropout_layer else nn.Identity()
         self.add_identity = add_identity
 
+    def _fused_first(self):
+        """Linear -> exact GELU -> Dropout(0 or eval): the pattern of every Swin block (depthformer_swin.py:451-459)."""
+        first = self.layers[0]
+        return (self.num_fcs == 2 and isinstance(first, nn.Sequential) and len(first) == 3 and type(first[0]) is Linear
+                and type(first[1]) is nn.GELU and getattr(first[1], 'approximate', 'none') == 'none'
+                and isinstance(first[2], nn.Dropout) and (first[2].p == 0 or not self.training))
+
     def forward(self, x, identity=None):
-        out = self.layers(x)
+        if x.is_cuda and self._fused_first():
+            lin = self.layers[0][0]
+            h = linear_bias_gelu(x, lin.weight, lin.bias)          # bias + GELU epilogue kernels (kernels.bias_gelu_*)
+            out = self.layers[2](self.layers[1](h))
+        else:
+            out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:

@@ -325,6 +325,15 @@ int ge_slice_rows_drop(const void* d_out, void* d_a, long rows, int Ca, int Co, 
                        unsigned long long seed, int dtype, void* stream);
 int ge_add_rows(const void* x, const float* pos, void* out, int B, long N, int C, int dtype, void* stream);
 int ge_colsum(const void* x, long R, int C, float* out, void* workspace, int accumulate, int dtype, void* stream);
+
+/* bias + GELU epilogue of the FFN's first Linear (mmcv FFN inside depth/models/backbones/depthformer_swin.py:451-459; GELU = exact
+ * erf form).  x (R, C) is the BIAS-FREE GEMM output (f32 / bf16, C a multiple of 4 / 8), bias (C) f32 or NULL.
+ *   ge_bias_gelu_fwd: out = gelu(x + bias)
+ *   ge_bias_gelu_bwd: dy = dg * gelu'(x + bias) (storage type) and d_bias (C) f32 = column sums of dy, one sweep;
+ *                     workspace: ge_nhwc_workspace(C, 1) bytes. */
+int ge_bias_gelu_fwd(const void* x, const float* bias, void* out, long R, int C, int dtype, void* stream);
+int ge_bias_gelu_bwd(const void* dg, const void* x, const float* bias, void* dy, float* d_bias, void* workspace, long R, int C,
+                     int dtype, void* stream);
 /* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
 size_t ge_nhwc_workspace(int C, int K);
 

@@ -1354,3 +1354,56 @@ def test_fused_adamw_bf16_shadow_tracks_parameters(dev):
     assert torch.equal(ps[0]._ge_lp, ps[0].detach().to(torch.bfloat16))
     plain = FusedAdamW([dict(params=[torch.randn(5, device=dev).requires_grad_(True)])], lr=1e-2, bf16_shadow=False)
     assert getattr(plain.arena, 'flat_shadow', None) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('R,C', [(777, 384), (12320, 1536), (5, 8), (1001, 3072)])
+def test_bias_gelu_epilogue(dev, dtype, R, C):
+    """ge_bias_gelu_fwd / _bwd (bias + exact-erf GELU epilogue of the FFN's first Linear, depthformer_swin.py:451-459) against
+    float64 torch: out = gelu(x + b); dy = dg * gelu'(x + b); d_bias = column sums of dy (of the ROUNDED dy: what the GEMMs read)."""
+    from gedepth_amd import kernels
+    g = gen(31)
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    x = (torch.randn(R, C, generator=g) * 2).to(td)
+    b = torch.randn(C, generator=g) * 0.5
+    dg = torch.randn(R, C, generator=g).to(td)
+    x64 = (x.double() + b.double()).requires_grad_(True)
+    ref = F.gelu(x64)
+    ref.backward(dg.double())
+    out = kernels.bias_gelu_fwd(x.to(dev), b.to(dev))
+    dy, db = kernels.bias_gelu_bwd(dg.to(dev), x.to(dev), b.to(dev))
+    tol = 1e-2 if dtype == 'bf16' else 2e-6
+    close_scaled(out.float(), ref, rel=tol, what='gelu(x + b)')
+    close_scaled(dy.float(), x64.grad, rel=tol, what='dy')
+    close_scaled(db, dy.float().cpu().double().sum(0), rel=1e-5, what='d_bias = column sums of the stored dy')
+    close_scaled(db, x64.grad.sum(0), rel=2e-2 if dtype == 'bf16' else 1e-5, what='d_bias vs float64')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('autocast', [False, True])
+def test_ffn_fused_bias_gelu_matches_composition(dev, autocast):
+    """mmrt.bricks.FFN with the bias + GELU epilogue kernels against the plain composition F.linear -> F.gelu -> F.linear + identity on
+    the same parameters: output and every gradient (fp32: to rounding; bf16 autocast: to bf16 rounding)."""
+    from gedepth_amd.mmrt.bricks import FFN
+    torch.manual_seed(0)
+    ffn = FFN(embed_dims=96, feedforward_channels=384, num_fcs=2, act_cfg=dict(type='GELU'), ffn_drop=0.,
+              dropout_layer=dict(type='DropPath', drop_prob=0.)).to(dev).train()
+    x = torch.randn(2, 1001, 96, device=dev)
+    go = torch.randn(2, 1001, 96, device=dev)
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        assert ffn._fused_first()
+        out = ffn(xa)
+    out.backward(go.to(out.dtype))
+    got = [out.float(), xa.grad] + [p.grad.clone() for p in ffn.parameters()]
+    for p in ffn.parameters():
+        p.grad = None
+    xb = x.clone().requires_grad_(True)
+    l0, l1 = ffn.layers[0][0], ffn.layers[1]
+    with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        ref = xb + F.linear(F.gelu(F.linear(xb, l0.weight, l0.bias)), l1.weight, l1.bias)
+    ref.backward(go.to(ref.dtype))
+    want = [ref.float(), xb.grad] + [p.grad.clone() for p in ffn.parameters()]
+    for a, b, n in zip(got, want, ['out', 'dx', 'dW1', 'db1', 'dW2', 'db2']):
+        close_scaled(a.float(), b.float(), rel=2e-2 if autocast else 2e-5, what=f'FFN {n}')
