@@ -21,6 +21,9 @@ class UpSample(nn.Sequential):
         self.convB = ConvModule(output_features, output_features, **kw)
 
     def forward(self, x, concat_with):
+        if x.is_cuda:                       # up-sampling written straight into the concat buffer (kernels.upcat, csrc/decoder.hip)
+            from ....kernels import upcat
+            return self.convB(self.convA(upcat(x, concat_with.to(x.dtype), align_corners=True)))
         up = resize(x, size=concat_with.shape[2:], mode='bilinear', align_corners=True)
         return self.convB(self.convA(torch.cat([up, concat_with.to(up.dtype)], dim=1)))
 

@@ -38,12 +38,14 @@ class _PETrunk(BaseModule):
 
     def trunk(self, inputs):
         xs = inputs[::-1]                       # coarse -> fine
-        size = xs[4].shape[2:]
+        ts = [self._conv(getattr(self, f'conv{i}'), xs[i]) for i in range(5)]
+        if ts[4].is_cuda:                       # four up-samplings + four adds in one pass over the fine map (kernels.upsum)
+            from ....kernels import upsum
+            return upsum(ts[4], ts[:4], align_corners=True)
+        size = ts[4].shape[2:]
         acc = None
         for i in range(5):
-            t = self._conv(getattr(self, f'conv{i}'), xs[i])
-            if i < 4:
-                t = resize(t, size=size, mode='bilinear', align_corners=True)
+            t = ts[i] if i == 4 else resize(ts[i], size=size, mode='bilinear', align_corners=True)
             acc = t if acc is None else acc + t
         return acc
 

@@ -69,6 +69,9 @@ SIGNATURES = {
     'ge_colsum': (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _vp]),
     'ge_bias_gelu_fwd': (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     'ge_bias_gelu_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    'ge_upcat_nhwc_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_upcat_nhwc_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_upsum_nhwc_fwd': (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_nhwc_workspace': (_sz, [_i, _i]),
     'ge_aug_load': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_depth': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

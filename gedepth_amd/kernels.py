@@ -4,6 +4,7 @@ PyTorch is used for device memory, streams and autograd plumbing only; every for
 backward below is a call into libgedepth_hip.so through gedepth_amd.hip (no eager fallback).
 """
 import ctypes
+import os
 
 import torch
 
@@ -84,6 +85,11 @@ def note_fallback(site, why=''):
 
 def _es(t):
     return t.element_size()
+
+
+# A/B switch for the fused passes added in round 3: GE_DISABLE=upcat,upsum,bias_gelu,msda_raw makes the named entry points take their
+# two-pass composition (still HIP kernels / library calls: a measurement aid for same-box comparisons, not a fall-back)
+DISABLED = {t for t in os.environ.get('GE_DISABLE', '').split(',') if t}
 
 
 def _tag(t):
@@ -349,7 +355,7 @@ def ms_deform_attn_raw(value, raw, reference_points, spatial_shapes, query_shape
     value (B,Nv,nH,64), raw (B,Nq,[nH*L*P*2 offsets | nH*L*P logits]) same dtype, reference points (B,Nq,L,2) -> (B,Nq,nH*64)."""
     B, Nv = value.shape[:2]
     Nq = raw.shape[1]
-    fused = (query_shapes is not None and MSDA_BINNED_BACKWARD and value.is_cuda and raw.dtype == value.dtype
+    fused = ('msda_raw' not in DISABLED and query_shapes is not None and MSDA_BINNED_BACKWARD and value.is_cuda and raw.dtype == value.dtype
              and value.dtype in (_f32, torch.bfloat16))
     if fused:
         arr, _ = _levels(spatial_shapes)
@@ -613,6 +619,91 @@ def bilinear_resize(x, size, align_corners=False):
     if x.shape[2] == Ho and x.shape[3] == Wo:
         return x
     return _Bilinear.apply(x, Ho, Wo, bool(align_corners))
+
+
+# -------------------------------------------------------------- decoder glue: up-sample + concat, sum of up-sampled maps
+class _UpCat(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, coarse, skip, align_corners):
+        N, Cu, Hc, Wc = coarse.shape
+        _, Cs, H, W = skip.shape
+        coarse, skip = _cl(coarse), _cl(skip)
+        out = torch.empty((N, Cu + Cs, H, W), device=coarse.device, dtype=coarse.dtype, memory_format=_CL)
+        PROFILER.run(f'upcat_fwd[{N}x({Cu}^+{Cs}) {Hc}x{Wc}->{H}x{W} {_tag(coarse)}]', (coarse.numel() + skip.numel() + out.numel()) * _es(out),
+                     lambda: hip.check(hip.lib().ge_upcat_nhwc_fwd(_raw_ptr(coarse, 'coarse'), _raw_ptr(skip, 'skip'), _raw_ptr(out, 'out'), N, Cu, Hc, Wc,
+                                                                    Cs, H, W, int(align_corners), hip.dtype_code(out), hip.stream()), 'ge_upcat_nhwc_fwd'))
+        ctx.geom = (N, Cu, Hc, Wc, Cs, H, W, int(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        N, Cu, Hc, Wc, Cs, H, W, ac = ctx.geom
+        d_out = _cl(d_out)
+        d_coarse = torch.empty((N, Cu, Hc, Wc), device=d_out.device, dtype=d_out.dtype, memory_format=_CL)
+        PROFILER.run(f'upcat_bwd[{N}x{Cu} {Hc}x{Wc}<-{H}x{W} {_tag(d_out)}]', (N * H * W * Cu + d_coarse.numel()) * _es(d_out),
+                     lambda: hip.check(hip.lib().ge_upcat_nhwc_bwd(_raw_ptr(d_out, 'd_out'), _raw_ptr(d_coarse, 'd_coarse'), N, Cu, Hc, Wc, Cs, H, W, ac,
+                                                                    hip.dtype_code(d_out), hip.stream()), 'ge_upcat_nhwc_bwd'))
+        return d_coarse, d_out[:, Cu:], None
+
+
+def upcat(coarse, skip, align_corners=True):
+    """``torch.cat([F.interpolate(coarse, size=skip.shape[2:], mode='bilinear', align_corners=...), skip], 1)`` in one pass on channels-last
+    maps (csrc/decoder.hip); the plain composition of the HIP bilinear kernel and ATen's cat for other layouts / channel counts."""
+    vn = 8 if skip.dtype == torch.bfloat16 else 4
+    if ('upcat' not in DISABLED and _cl_ok(skip) and coarse.is_cuda and coarse.dtype == skip.dtype and coarse.shape[1] % vn == 0 and coarse.shape[1] > 1
+            and coarse.shape[0] * skip.shape[2] <= 65535 and tuple(coarse.shape[2:]) != tuple(skip.shape[2:])):
+        return _UpCat.apply(coarse, skip, bool(align_corners))
+    return torch.cat([bilinear_resize(coarse, skip.shape[2:], align_corners), skip], 1)
+
+
+class _UpSum(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, align_corners, fine, *srcs):
+        N, C, H, W = fine.shape
+        fine = _cl(fine)
+        srcs = [_cl(t) for t in srcs]
+        out = torch.empty_like(fine)
+        ptrs = (ctypes.c_void_p * len(srcs))(*[_raw_ptr(t, 'src') for t in srcs])
+        hw = (ctypes.c_int * (2 * len(srcs)))(*[v for t in srcs for v in t.shape[2:]])
+        PROFILER.run(f'upsum_fwd[{N}x{C}x{H}x{W} <- {len(srcs)} maps {_tag(fine)}]', (2 * fine.numel() + sum(t.numel() for t in srcs)) * _es(fine),
+                     lambda: hip.check(hip.lib().ge_upsum_nhwc_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), len(srcs),
+                                                                    _raw_ptr(fine, 'fine'), _raw_ptr(out, 'out'), N, C, H, W, int(align_corners),
+                                                                    hip.dtype_code(fine), hip.stream()), 'ge_upsum_nhwc_fwd'))
+        ctx.geom = (N, C, H, W, int(align_corners), [tuple(t.shape[2:]) for t in srcs])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        N, C, H, W, ac, sizes = ctx.geom
+        d_out = _cl(d_out)
+        grads = []
+        for (Hi, Wi) in sizes:                               # the transpose of each interpolation reads the same d_out
+            d_in = torch.empty((N, C, Hi, Wi), device=d_out.device, dtype=d_out.dtype, memory_format=_CL)
+            ws = torch.empty(N * H * Wi * C, device=d_out.device, dtype=_f32) if (H > 3 * Hi or W > 3 * Wi) else None
+            PROFILER.run(f'bilinear_nhwc_bwd[{N}x{C} {Hi}x{Wi}<-{H}x{W} {_tag(d_out)}]', (d_out.numel() + d_in.numel()) * _es(d_out),
+                         lambda: hip.check(hip.lib().ge_bilinear_nhwc_bwd(_raw_ptr(d_out, 'd_out'), _raw_ptr(d_in, 'd_in'), hip.ptr(ws),
+                                                                          0 if ws is None else ws.numel() * 4, N, C, Hi, Wi, H, W, ac,
+                                                                          hip.dtype_code(d_out), hip.stream()), 'ge_bilinear_nhwc_bwd'))
+            grads.append(d_in)
+        return (None, d_out) + tuple(grads)
+
+
+def upsum(fine, coarse_maps, align_corners=True):
+    """``((up(c0) + up(c1)) + ...) + fine`` with ``up = F.interpolate(., size=fine.shape[2:], bilinear)``: one pass over the fine map
+    (csrc/decoder.hip) instead of one up-sampled tensor and one add per coarse map."""
+    vn = 8 if fine.dtype == torch.bfloat16 else 4
+    ok = ('upsum' not in DISABLED and _cl_ok(fine) and 1 <= len(coarse_maps) <= 4 and fine.shape[0] * fine.shape[2] <= 65535
+          and all(t.is_cuda and t.dtype == fine.dtype and t.shape[1] == fine.shape[1] and t.shape[1] % vn == 0 and tuple(t.shape[2:]) != tuple(fine.shape[2:])
+                  for t in coarse_maps))
+    if not ok:
+        acc = None
+        for t in coarse_maps:
+            t = bilinear_resize(t, fine.shape[2:], align_corners)
+            acc = t if acc is None else acc + t
+        return fine if acc is None else acc + fine
+    return _UpSum.apply(bool(align_corners), fine, *coarse_maps)
 
 
 # ------------------------------------------------------------------------------ layer norm

@@ -334,6 +334,22 @@ int ge_colsum(const void* x, long R, int C, float* out, void* workspace, int acc
 int ge_bias_gelu_fwd(const void* x, const float* bias, void* out, long R, int C, int dtype, void* stream);
 int ge_bias_gelu_bwd(const void* dg, const void* x, const float* bias, void* dy, float* d_bias, void* workspace, long R, int C,
                      int dtype, void* stream);
+
+/* Bandwidth-bound decoder glue fused into one pass each (csrc/decoder.hip), channels-last maps (N, H, W, C), C multiples of the
+ * 16-byte vector, f32 / bf16:
+ *   ge_upcat_nhwc_fwd  out (N,H,W,Cu+Cs) = [bilinear(coarse (N,Hc,Wc,Cu) -> H x W) | skip (N,H,W,Cs)]: the UpSample block of the
+ *                      DenseDepth head (depth/models/decode_heads/densedepth_head.py:25-27: F.interpolate -> torch.cat) without the
+ *                      up-sampled intermediate and without ATen's cat;
+ *   ge_upcat_nhwc_bwd  d_coarse from the d_up columns of d_out read in place (row pitch Cu + Cs); d_skip is a channel slice of d_out;
+ *   ge_upsum_nhwc_fwd  out = fine + sum_i bilinear(src_i -> H x W), nsrc <= 4: the trunk of the PE necks
+ *                      (depth/models/necks/pemask_neck.py:52-64, dynamicpe_neck.py:512-539); partial sums are rounded to the storage
+ *                      type in the reference's order.  hw = {H_0, W_0, H_1, W_1, ...}.  Backward: ge_bilinear_nhwc_bwd per source. */
+int ge_upcat_nhwc_fwd(const void* coarse, const void* skip, void* out, int N, int Cu, int Hc, int Wc, int Cs, int H, int W,
+                      int align_corners, int dtype, void* stream);
+int ge_upcat_nhwc_bwd(const void* d_out, void* d_coarse, int N, int Cu, int Hc, int Wc, int Cs, int H, int W, int align_corners,
+                      int dtype, void* stream);
+int ge_upsum_nhwc_fwd(const void* const* srcs, const int* hw, int nsrc, const void* fine, void* out, int N, int C, int H, int W,
+                      int align_corners, int dtype, void* stream);
 /* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
 size_t ge_nhwc_workspace(int C, int K);
 

@@ -1407,3 +1407,70 @@ def test_ffn_fused_bias_gelu_matches_composition(dev, autocast):
     want = [ref.float(), xb.grad] + [p.grad.clone() for p in ffn.parameters()]
     for a, b, n in zip(got, want, ['out', 'dx', 'dW1', 'db1', 'dW2', 'db2']):
         close_scaled(a.float(), b.float(), rel=2e-2 if autocast else 2e-5, what=f'FFN {n}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('geom', [(2, 96, 64, (11, 18), (22, 35)), (1, 768, 384, (3, 5), (6, 9)), (2, 8, 8, (5, 7), (9, 13)), (2, 16, 24, (1, 2), (2, 3))])
+def test_upcat_matches_interpolate_cat(dev, dtype, geom):
+    """kernels.upcat (ge_upcat_nhwc_*: the UpSample block's F.interpolate(align_corners=True) -> torch.cat, densedepth_head.py:25-27,
+    as one pass into the concat buffer) against torch on the CPU in float64: forward, d_coarse (the transposed interpolation read
+    from the concat gradient in place) and d_skip; exact 2x, non-integer factors and a 1-row coarse map."""
+    from gedepth_amd import kernels
+    N, Cu, Cs, (Hc, Wc), (H, W) = geom
+    g = gen(41)
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    coarse = torch.randn(N, Cu, Hc, Wc, generator=g).to(td)
+    skip = torch.randn(N, Cs, H, W, generator=g).to(td)
+    go = torch.randn(N, Cu + Cs, H, W, generator=g).to(td)
+    c64, s64 = coarse.double().requires_grad_(True), skip.double().requires_grad_(True)
+    ref = torch.cat([F.interpolate(c64, size=(H, W), mode='bilinear', align_corners=True), s64], 1)
+    ref.backward(go.double())
+    cg = coarse.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sg = skip.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    kernels.PROFILER.enable()
+    out = kernels.upcat(cg, sg, align_corners=True)
+    out.backward(go.to(dev))
+    kernels.PROFILER.disable()
+    assert any(r['name'].startswith('upcat_fwd') for r in kernels.PROFILER.summary()) and kernels._is_cl(out)
+    tol = 1e-2 if dtype == 'bf16' else 1e-5
+    close_scaled(out.float(), ref, rel=tol, what='upcat')
+    close_scaled(cg.grad.float(), c64.grad, rel=tol, what='d coarse')
+    close_scaled(sg.grad.float(), s64.grad, rel=tol, what='d skip')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_upsum_matches_pe_trunk_composition(dev, dtype):
+    """kernels.upsum (ge_upsum_nhwc_fwd: the PE-neck trunk's four align_corners up-samplings + adds in one pass, pemask_neck.py:52-64)
+    against float64 torch, forward and the gradient of every map (factors 16, 8, 4, 2: separable and direct transposes)."""
+    from gedepth_amd import kernels
+    g = gen(43)
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    sizes = [(2, 3), (4, 6), (8, 12), (16, 24)]
+    H, W, C, N = 32, 48, 64, 2
+    coarse = [torch.randn(N, C, h, w, generator=g).to(td) for h, w in sizes]
+    fine = torch.randn(N, C, H, W, generator=g).to(td)
+    go = torch.randn(N, C, H, W, generator=g).to(td)
+    c64 = [t.double().requires_grad_(True) for t in coarse]
+    f64 = fine.double().requires_grad_(True)
+    ref = f64
+    acc = None
+    for t in c64:
+        u = F.interpolate(t, size=(H, W), mode='bilinear', align_corners=True)
+        acc = u if acc is None else acc + u
+    ref = acc + f64
+    ref.backward(go.double())
+    cl = torch.channels_last
+    cg = [t.to(dev).contiguous(memory_format=cl).requires_grad_(True) for t in coarse]
+    fg = fine.to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    kernels.PROFILER.enable()
+    out = kernels.upsum(fg, cg, align_corners=True)
+    out.backward(go.to(dev))
+    kernels.PROFILER.disable()
+    assert any(r['name'].startswith('upsum_fwd') for r in kernels.PROFILER.summary())
+    tol = 2e-2 if dtype == 'bf16' else 1e-5
+    close_scaled(out.float(), ref, rel=tol, what='upsum')
+    close_scaled(fg.grad.float(), f64.grad, rel=tol, what='d fine')
+    for a, b, s in zip(cg, c64, sizes):
+        close_scaled(a.grad.float(), b.grad, rel=tol, what=f'd coarse {s}')
