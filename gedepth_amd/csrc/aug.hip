@@ -204,3 +204,83 @@ extern "C" int ge_aug_color_normalize(const float* src, float* dst, int H, int W
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- DDAD front end (DDADResize)
+// depth/datasets/pipelines/transforms.py:735-783: the 1216 x 1936 frame is brought to 384 x 640 BEFORE the shared augmentation chain:
+// colour by cv2.INTER_AREA (pixel-area averaging, uint8 in / uint8 out), the two ground-depth channels by cv2.INTER_NEAREST, and the
+// sparse LiDAR depth / slope classes by re-projecting every valid pixel to int(coord * scale) — later pixels (row-major) overwrite
+// earlier ones, nothing is interpolated.
+//
+// Area filter: destination cell j covers the source interval [j s, (j + 1) s), s = in / out; source pixel i weighs by its overlap,
+// weights normalised per cell, float64 (imageops._area_weights); rows first, then columns; the uint8 result is rint + clip.
+__device__ __forceinline__ void area_span(int j, int n_in, int n_out, int& i0, int& i1, double& lo, double& hi, double& inv) {
+  const double s = (double)n_in / (double)n_out;
+  lo = (double)j * s; hi = (double)(j + 1) * s;
+  i0 = (int)floor(lo);
+  i1 = (int)ceil(hi);
+  if (i1 > n_in) i1 = n_in;
+  double tot = 0.0;
+  for (int i = i0; i < i1; ++i) tot += fmin(hi, (double)(i + 1)) - fmax(lo, (double)i);
+  inv = 1.0 / tot;
+}
+// src: (H, W, 3) uint8 HWC -> dst: (3, Ho, Wo) planar f32 holding the uint8-rounded averages
+__global__ void __launch_bounds__(256) aug_area_u8_k(const uint8_t* __restrict__ src, float* __restrict__ dst, int H, int W, int Ho, int Wo) {
+  const long n = (long)Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int y = (int)(i / Wo), x = (int)(i - (long)y * Wo);
+    int y0, y1, x0, x1;
+    double ylo, yhi, yinv, xlo, xhi, xinv;
+    area_span(y, H, Ho, y0, y1, ylo, yhi, yinv);
+    area_span(x, W, Wo, x0, x1, xlo, xhi, xinv);
+    // host order: out[oh, w] = sum_h Wy[oh, h] src[h, w] (float64), then out[oh, ow] = sum_w Wx[ow, w] out[oh, w]
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int xx = x0; xx < x1; ++xx) {
+      const double wx = (fmin(xhi, (double)(xx + 1)) - fmax(xlo, (double)xx)) * xinv;
+      double col[3] = {0.0, 0.0, 0.0};
+      for (int yy = y0; yy < y1; ++yy) {
+        const double wy = (fmin(yhi, (double)(yy + 1)) - fmax(ylo, (double)yy)) * yinv;
+        const uint8_t* p = src + ((long)yy * W + xx) * 3;
+        col[0] += wy * (double)p[0]; col[1] += wy * (double)p[1]; col[2] += wy * (double)p[2];
+      }
+      acc[0] += wx * col[0]; acc[1] += wx * col[1]; acc[2] += wx * col[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[c * n + i] = (float)fmin(fmax(rint(acc[c]), 0.0), 255.0);
+  }
+}
+extern "C" int ge_aug_area_u8(const uint8_t* src_hwc, float* dst, int H, int W, int Ho, int Wo, void* stream) {
+  if (!src_hwc || !dst || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return GE_ERR_BAD_ARG;
+  if (Ho > H || Wo > W) return GE_ERR_UNSUPPORTED;               // the area filter is the shrinking branch (DDAD: 1216 x 1936 -> 384 x 640)
+  aug_area_u8_k<<<ge_blocks((long)Ho * Wo, 256, 65536), 256, 0, ge_stream(stream)>>>(src_hwc, dst, H, W, Ho, Wo);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+// Sparse re-projection as a deterministic gather: dst[Y, X] = the LAST source pixel in row-major order with src > 0,
+// (int)(y * (Ho / H)) == Y and (int)(x * (Wo / W)) == X (float64 product, truncation: numpy's int64 * float -> astype(int32)), else 0.
+__global__ void __launch_bounds__(256) aug_splat_k(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Ho, int Wo) {
+  const double sy = (double)Ho / (double)H, sx = (double)Wo / (double)W;
+  const long n = (long)Ho * Wo;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int Y = (int)(i / Wo), X = (int)(i - (long)Y * Wo);
+    int ylo = (int)floor((double)Y / sy) - 1, yhi = (int)ceil((double)(Y + 1) / sy) + 1;
+    int xlo = (int)floor((double)X / sx) - 1, xhi = (int)ceil((double)(X + 1) / sx) + 1;
+    ylo = max(ylo, 0); xlo = max(xlo, 0); yhi = min(yhi, H - 1); xhi = min(xhi, W - 1);
+    float v = 0.f;
+    bool found = false;
+    for (int y = yhi; y >= ylo && !found; --y) {
+      if ((int)((double)y * sy) != Y) continue;
+      for (int x = xhi; x >= xlo; --x) {
+        if ((int)((double)x * sx) != X) continue;
+        const float s = src[(long)y * W + x];
+        if (s > 0.f) { v = s; found = true; break; }
+      }
+    }
+    dst[i] = v;
+  }
+}
+extern "C" int ge_aug_splat(const float* src, float* dst, int H, int W, int Ho, int Wo, void* stream) {
+  if (!src || !dst || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return GE_ERR_BAD_ARG;
+  aug_splat_k<<<ge_blocks((long)Ho * Wo, 256, 65536), 256, 0, ge_stream(stream)>>>(src, dst, H, W, Ho, Wo);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}

@@ -176,7 +176,9 @@ class KITTIGPUPipeline:
                                        hip.stream()), 'ge_aug_rotate')
         return out
 
-    def __call__(self, sample, params):
+    def _front(self, sample):
+        """Decoded files -> the planar maps the augmentation chain works on: img (5, h, w), depth (1, h, w) | None, slope classes
+        (1, h, w) | None, pe_ori_point.  KITTI: KB crop window (transforms.py:150-205)."""
         dev = self.device
         bgr = sample['bgr'].to(dev, non_blocking=True).contiguous()
         H, W = bgr.shape[:2]
@@ -195,6 +197,11 @@ class KITTIGPUPipeline:
             if tuple(kmap.shape) != (H, W):                                          # loading.py:146: nearest resize to the depth map
                 kmap = self._resize(kmap[None], (H, W), 0)[0]
             k = self._window(kmap[None], (kh, kw), top, left, fill=255.0)
+        return img, depth, k, pe[-1, -1]
+
+    def __call__(self, sample, params):
+        img, depth, k, pe_ori_point = self._front(sample)
+        kh, kw = self.kb_crop
         maps = [(img, 1, 0.0), (depth, 0, 0.0), (k, 0, 255.0)]                        # (planes, interpolation, border / fill)
         # Resize
         maps = [(None if x is None else self._resize(x, params['resize'], mode), mode, fill) for x, mode, fill in maps]
@@ -217,7 +224,7 @@ class KITTIGPUPipeline:
                                                 ctypes.cast(colors, ctypes.c_void_p), ctypes.cast(self.mean, ctypes.c_void_p),
                                                 ctypes.cast(self.std, ctypes.c_void_p), self.pe_depth_scale, int(self.to_rgb),
                                                 hip.stream()), 'ge_aug_color_normalize')
-        out = dict(img=out_img, pe_ori_point=pe[-1, -1],
+        out = dict(img=out_img, pe_ori_point=pe_ori_point,
                    img_metas=dict(filename=sample['filename'], ori_filename=sample['ori_filename'], ori_shape=(kh, kw, 5),
                                   img_shape=tuple(out_img.shape[1:]) + (5,), pad_shape=tuple(out_img.shape[1:]) + (5,),
                                   flip=params['flip'], flip_direction='horizontal'))
@@ -225,6 +232,8 @@ class KITTIGPUPipeline:
             out['depth_gt'] = depth
         if k is not None:
             out['pe_k_gt'] = k[0]
+        if 'height' in sample:
+            out['height'] = torch.tensor(float(sample['height']), device=self.device)
         return out
 
     def batch(self, samples):
@@ -232,3 +241,82 @@ class KITTIGPUPipeline:
         data = {k: torch.stack([o[k] for o in outs], 0) for k in outs[0] if k != 'img_metas'}
         data['img_metas'] = [o['img_metas'] for o in outs]
         return data
+
+
+# ------------------------------------------------------------------------------------------------ DDAD
+@DATASETS.register_module()
+class DDADRawDataset:
+    """File decoding only for DDAD (what LoadDDADImageFromFile / DDADDepthLoadAnnotations read, loading.py:743-955): uint8 BGR frame,
+    the float32 sparse depth of the .npz, the slope classes (+5, 255 = ignore), camera name and height."""
+
+    def __init__(self, split, cameras=('CAMERA_01', 'CAMERA_05', 'CAMERA_06', 'CAMERA_09'), pipeline=None, **kw):
+        from .ddad import DDADDataset
+        self._ds = DDADDataset(pipeline=[], cameras=cameras, split=split, **kw)
+        self.img_infos = self._ds.img_infos
+
+    def __len__(self):
+        return len(self.img_infos)
+
+    def __getitem__(self, idx):
+        from .pipelines.loading import _DDAD_CAMERA_HEIGHT
+        info = self.img_infos[idx]
+        filename = info['filename']
+        bgr = np.ascontiguousarray(np.asarray(Image.open(filename).convert('RGB'))[..., ::-1])
+        depth_file = info['ann']['depth_map']
+        camera = depth_file.split('/')[-2]
+        out = dict(filename=filename, ori_filename=filename, date=camera, camera=camera, bgr=torch.from_numpy(bgr),
+                   height=next(h for cam, h in _DDAD_CAMERA_HEIGHT.items() if cam in filename))
+        if osp.isfile(depth_file):
+            out['depth'] = torch.from_numpy(np.load(depth_file)['depth'].astype(np.float32))
+            k_file = depth_file.replace('depth_val', 'depth').replace('.npz', '_slope_public_debug.npz')
+            if osp.isfile(k_file):
+                k = np.load(k_file)['k_img'].astype(np.float32)
+                ignore = k == 255
+                k = k + 5
+                k[ignore] = 255
+                out['pe_k'] = torch.from_numpy(k)
+        return out
+
+
+class DDADGPUPipeline(KITTIGPUPipeline):
+    """The DDAD training pipeline (configs/_base_/datasets/ddad_gedepth.py) on the device: DDADResize's area / nearest / sparse
+    re-projection front end (ge_aug_area_u8, ge_aug_resize, ge_aug_splat: transforms.py:735-783) to ``shape``, then the shared chain
+    Resize -> Padding -> RandomRotate -> RandomFlip(prob 0) -> RandomCrop -> ColorAug -> Normalize(depth_scale = 250) of aug.hip.  The
+    per-camera ground depth ``<pe_root>/<camera>/ddad_pe.npz`` is uploaded once per camera."""
+
+    def __init__(self, pe_root, shape=(384, 640), device='cuda', pe_depth_scale=250.0, **kw):
+        kw.setdefault('flip_prob', 0.0)
+        super().__init__(data_root=None, img_dir='', device=device, pe_source='npy', pe_depth_scale=pe_depth_scale, kb_crop=tuple(shape),
+                         crop_size=tuple(shape), **kw)
+        self.pe_root = pe_root
+
+    def ground_depth(self, camera, H, W):
+        key = (camera, H, W)
+        if key not in self._pe:
+            pe = np.load(osp.join(self.pe_root, camera, 'ddad_pe.npz'))['pe'].astype(np.float32)
+            assert pe.shape == (H, W), (pe.shape, H, W)
+            self._pe[key] = torch.from_numpy(pe).to(self.device).contiguous()
+        return self._pe[key]
+
+    def _front(self, sample):
+        dev = self.device
+        bgr = sample['bgr'].to(dev, non_blocking=True).contiguous()
+        H, W = bgr.shape[:2]
+        oh, ow = self.kb_crop
+        pe_raw = self.ground_depth(sample['camera'], H, W)
+        img = _planes(5, oh, ow, dev)
+        hip.check(_lib().ge_aug_area_u8(hip.ptr(bgr), hip.ptr(img), H, W, oh, ow, hip.stream()), 'ge_aug_area_u8')
+        pe = pe_raw.clone()                                                         # LoadDDADImageFromFile: channel 3 = pe with (250, inf) and (-inf, 0) zeroed
+        pe[pe > 250] = 0
+        pe[pe < 0] = 0
+        img[3:5] = self._resize(torch.stack((pe, pe_raw)), (oh, ow), 0)             # cv2.INTER_NEAREST
+        depth = k = None
+        if 'depth' in sample:
+            d = sample['depth'].to(dev, non_blocking=True).contiguous()
+            depth = _planes(1, oh, ow, dev)
+            hip.check(_lib().ge_aug_splat(hip.ptr(d), hip.ptr(depth), d.shape[0], d.shape[1], oh, ow, hip.stream()), 'ge_aug_splat')
+        if 'pe_k' in sample:
+            kk = sample['pe_k'].to(dev, non_blocking=True).contiguous()
+            k = _planes(1, oh, ow, dev)
+            hip.check(_lib().ge_aug_splat(hip.ptr(kk), hip.ptr(k), kk.shape[0], kk.shape[1], oh, ow, hip.stream()), 'ge_aug_splat')
+        return img, depth, k, pe_raw[-1, -1]

@@ -4,9 +4,12 @@ depth/datasets/pipelines/transforms.py:30-47 (Normalize), :249-286 (RandomRotate
 and loading.py:146 (nearest resize of the slope-class map).
 
 Parity status: cv2 is not installed in the build image, so these are restated from OpenCV's documented sampling rules
-(half-pixel-centre bilinear without antialiasing, ``floor(dst * scale)`` nearest, inverse-mapped affine warp with a
-constant border) and are NOT pinned against cv2 output; OpenCV's warpAffine additionally quantises source coordinates to
-1/32 pixel, which is not reproduced.
+(half-pixel-centre bilinear without antialiasing, ``floor(dst * scale)`` nearest, inverse-mapped affine warp with a constant
+border, pixel-area averaging) and pinned against INDEPENDENT implementations of those rules in tests/test_imageops_independent.py:
+scipy.ndimage.map_coordinates / affine_transform (generic samplers driven by the coordinate rules), PIL's float-mode resize /
+rotate / BOX filter, and brute-force supersampling for the area filter.  What OpenCV does beyond the rules is fixed-point
+arithmetic — warpAffine quantises source coordinates to 1/32 pixel, uint8 resize uses 11-bit weights — which is not reproduced;
+the resulting bound (|slope| / 32 per axis, one grey level) is stated in that test file.
 """
 import numpy as np
 import torch

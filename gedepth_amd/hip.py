@@ -79,6 +79,8 @@ SIGNATURES = {
     'ge_aug_rotate': (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _i, _vp]),
     'ge_aug_window': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_color_normalize': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _f, _i, _vp]),
+    'ge_aug_area_u8': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'ge_aug_splat': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'ge_silog_stats': (_i, [_vp, _vp, _f, _vp, _l, _vp]),
     'ge_silog_bwd': (_i, [_vp, _vp, _f, _vp, _vp, _vp, _l, _vp]),
     'ge_sumsq': (_i, [_vp, _l, _vp, _vp]),

@@ -383,6 +383,13 @@ int ge_aug_window(const float* src, float* dst, int C, int Hs, int Ws, int Hd, i
 int ge_aug_color_normalize(const float* src, float* dst, int H, int W, int color_on, float gamma, float brightness,
                            const double* colors3, const double* mean3, const double* std3, float depth_scale,
                            int to_rgb, void* stream);
+/* DDAD front end of the device pipeline (DDADResize, depth/datasets/pipelines/transforms.py:735-783):
+ *   ge_aug_area_u8  (H, W, 3) uint8 -> (3, Ho, Wo) planar f32 = cv2.INTER_AREA shrink (pixel-area averaging, float64 weights, rint + clip)
+ *   ge_aug_splat    sparse map (H, W) f32 -> (Ho, Wo): every pixel > 0 re-projected to int(coord * scale); the last source pixel in
+ *                   row-major order wins (deterministic gather), the rest is 0
+ * (the ground-depth channels take ge_aug_resize with mode 0 = nearest). */
+int ge_aug_area_u8(const uint8_t* src_hwc, float* dst, int H, int W, int Ho, int Wo, void* stream);
+int ge_aug_splat(const float* src, float* dst, int H, int W, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SiLog loss statistics (fp32 in, fp64 accumulate), SigLoss.sigloss

@@ -526,6 +526,28 @@ def encode_decode(img, P, cfg, min_depth=1e-3, max_depth=80.0, height=1.65):
     return F.interpolate(out, size=img.shape[2:], mode='bilinear', align_corners=True)
 
 
+def inference(img, img_meta, P, cfg, **kw):
+    """inference + whole_inference, encoder_decoder.py:196-235: encode_decode, rescale to ``ori_shape`` (bilinear, the head's
+    ``align_corners``), and the prediction of a flipped view flipped back."""
+    out = encode_decode(img, P, cfg, **kw)
+    ori = tuple(img_meta[0]['ori_shape'][:2])
+    if tuple(out.shape[2:]) != ori:
+        out = F.interpolate(out, size=ori, mode='bilinear', align_corners=True)
+    if img_meta[0].get('flip'):
+        direction = img_meta[0]['flip_direction']
+        assert direction in ('horizontal', 'vertical')
+        out = out.flip(dims=(3,)) if direction == 'horizontal' else out.flip(dims=(2,))
+    return out
+
+
+def aug_test(imgs, img_metas, P, cfg, **kw):
+    """aug_test, encoder_decoder.py:249-274 (flip test-time augmentation): the mean of ``inference`` over the augmented views."""
+    pred = inference(imgs[0], img_metas[0], P, cfg, **kw)
+    for i in range(1, len(imgs)):
+        pred = pred + inference(imgs[i], img_metas[i], P, cfg, **kw)
+    return pred / len(imgs)
+
+
 def parse_losses(losses):
     """BaseDepther._parse_losses (single process), depther/base.py:170-204."""
     log_vars = {k: v.mean() for k, v in losses.items()}

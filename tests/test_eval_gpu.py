@@ -57,6 +57,38 @@ def test_eigen_protocol_with_flip_tta(setup):
     assert np.allclose(preds[0], 0.5 * (single + flipped), rtol=1e-4, atol=1e-4)
 
 
+def test_flip_tta_prediction_vs_oracle(setup):
+    """The product's whole test path — dataset pipeline (KB crop, MultiScaleFlipAug with flip), ``single_gpu_test``, the model's
+    ``aug_test`` / ``inference`` / flip-back — against the CPU oracle's restatement of encoder_decoder.py:196-274 (oracle.aug_test)
+    fed with the SAME pipeline tensors and the same weights: fp32, exact-fp32 window attention, 1e-4 relative on every pixel."""
+    from oracle import gedepth_oracle as O
+    cfg, model = setup
+    ds = build_dataset(cfg.data.test, dict(test_mode=True))
+    loader = build_dataloader(ds, 1, 0, dist=False, shuffle=False)
+    batch = next(iter(loader))
+    assert len(batch['img']) == 2 and batch['img_metas'][1][0]['flip'] and not batch['img_metas'][0][0]['flip']
+    variants = []
+    for mod in model.modules():
+        if hasattr(mod, 'kernel_variant'):
+            variants.append((mod, mod.kernel_variant))
+            mod.kernel_variant = 1
+    try:
+        model.eval()
+        with torch.no_grad():
+            got = model([t.cuda() for t in batch['img']], batch['img_metas'], return_loss=False,
+                        pe_ori_point=[t.cuda() for t in batch['pe_ori_point']])[0]
+    finally:
+        for mod, v in variants:
+            mod.kernel_variant = v
+    P = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = O.aug_test([t.float() for t in batch['img']], batch['img_metas'], P, dict(O.SWIN_T, adaptive=False))[0].numpy()
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+    print(f'\n[flip-TTA 352x1216 vs oracle] max rel {rel.max():.2e} mean {rel.mean():.2e}')
+    assert got.shape == ref.shape == (1, 352, 1216)
+    assert rel.max() <= 2e-4 and rel.mean() <= 1e-5, (rel.max(), rel.mean())          # two fp32 evaluations, as in test_full_size_forward_vs_oracle
+
+
 def test_train_step_on_pipeline_batch(setup):
     cfg, model = setup
     random.seed(0); np.random.seed(0)

@@ -173,3 +173,59 @@ def test_batches_feed_a_training_step(tmp_path):
         assert np.isfinite(out['log_vars']['loss'])
         n += 1
     assert n == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(48, 80), (36, 64)])
+def test_ddad_device_pipeline_matches_host_pipeline(tmp_path, shape):
+    """DDAD on the device pipeline (DDADGPUPipeline: ge_aug_area_u8 / nearest / ge_aug_splat front end = DDADResize,
+    transforms.py:735-783, then the shared augmentation kernels) against the host pipeline — whose image operations are pinned against
+    scipy / PIL in tests/test_imageops_independent.py — on the toy DDAD tree with identical seeded draws; integer (2x) and non-integer
+    (2.67 x 2.5) shrink factors.  Depth and slope classes (index-only: re-projection, nearest, pad, crop) are bit-exact."""
+    from test_dataset_cpu import _make_toy_ddad
+    from gedepth_amd.depth.datasets import build_dataset
+    from gedepth_amd.depth.datasets.gpu_pipeline import DDADGPUPipeline, DDADRawDataset, draw_params
+    root = str(tmp_path)
+    split = _make_toy_ddad(root, frames=2)
+    norm = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+    pipeline = [
+        dict(type='LoadDDADImageFromFile', USEPE=True, USE_DYNAMIC_PE=True, pe_root=os.path.join(root, 'pe')),
+        dict(type='DDADDepthLoadAnnotations', USE_DYNAMIC_PE=True),
+        dict(type='DDADResize', shape=shape, USE_DYNAMIC_PE=True),
+        dict(type='Resize', ratio_range=(0.5, 2.0)),
+        dict(type='Padding', img_padding_value=(0, 0, 0), depth_padding_value=255, pe_k=True, ori_h=shape[0], ori_w=shape[1]),
+        dict(type='RandomRotate', prob=0.5, degree=2.5),
+        dict(type='RandomFlip', prob=0.0),
+        dict(type='RandomCrop', crop_size=shape),
+        dict(type='ColorAug', prob=0.5, gamma_range=[0.9, 1.1], brightness_range=[0.9, 1.1], color_range=[0.9, 1.1]),
+        dict(type='Normalize', depth_scale=250, **norm),
+        dict(type='DefaultFormatBundle'),
+        dict(type='Collect', keys=['img', 'depth_gt', 'pe_k_gt', 'height'], meta_keys=('filename', 'flip')),
+    ]
+    cams = ['CAMERA_%02d' % i for i in (1, 5, 6, 9)]
+    host = build_dataset(dict(type='DDADDataset', pipeline=pipeline, split=split, max_depth=200, cameras=cams))
+    raw = DDADRawDataset(split=split, cameras=cams)
+    pipe = DDADGPUPipeline(pe_root=os.path.join(root, 'pe'), shape=shape)
+    assert len(raw) == len(host) == 4
+    seen = dict(pad=0, rotate=0, color=0, up=0)
+    for seed in range(10):
+        idx = seed % len(host)
+        np.random.seed(200 + seed); random.seed(200 + seed)
+        ref = host[idx]
+        np.random.seed(200 + seed); random.seed(200 + seed)
+        params = draw_params(shape[0], shape[1], canvas=shape, crop_size=shape, flip_prob=0.0)
+        out = pipe(raw[idx], params)
+        for k, hit in (('pad', params['pad'] is not None), ('rotate', params['rotate'] is not None), ('color', params['color'] is not None),
+                       ('up', params['resize'][0] > shape[0])):
+            seen[k] += int(hit)
+        img, img_ref = out['img'].cpu(), ref['img']
+        assert img.shape == img_ref.shape == (5,) + tuple(shape) and not params['flip']
+        assert torch.equal(out['pe_k_gt'].cpu(), ref['pe_k_gt']), f'seed {seed}: slope classes differ'
+        assert torch.equal(out['depth_gt'].cpu().double(), ref['depth_gt'].double()), f'seed {seed}: depth differs'
+        assert float(out['height']) == pytest.approx(float(ref['height']))
+        for c in (3, 4):
+            err = (img[c] - img_ref[c]).abs()
+            assert err.max().item() <= 1e-5 * max(1.0, img_ref[c].abs().max().item()), (seed, c, err.max().item())
+        err = (img[:3] - img_ref[:3]).abs()                                            # one uint8 step of the truncation inside Normalize = 1 / 57
+        assert err.max().item() <= 0.0176 and (err > 1e-5).float().mean().item() <= 5e-3, (seed, err.max().item(), (err > 1e-5).float().mean().item())
+    assert all(v > 0 for v in seen.values()), seen
