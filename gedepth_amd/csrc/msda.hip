@@ -245,6 +245,9 @@ __global__ void __launch_bounds__(256) msda_bwd_k(const T* __restrict__ value, M
 #ifndef MSDA_LW_WAVES
 #define MSDA_LW_WAVES 4
 #endif
+#ifndef MSDA_LW_PRE
+#define MSDA_LW_PRE 1
+#endif
 #define MSDA_LW_ATTR __attribute__((amdgpu_waves_per_eu(MSDA_LW_WAVES, MSDA_LW_WAVES)))
 // EMIT = true (L == 4, P == 8): the kernel writes the gradient of the RAW projection outputs instead of d_loc / d_attw —
 // d_off_raw = d_loc / (W_l, H_l) and d_logit_raw = attw * (d_attw - sum_{l,p} attw * d_attw) (mmcv's view / normaliser / softmax
@@ -303,6 +306,48 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
       const float s_dy = bx * (d10 - d00) + ax * (d11 - d01);                                             \
       sv_ = s_val; sx_ = s_dx * (wgt * (float)Wl); sy_ = s_dy * (wgt * (float)Hl);                        \
     }
+    // Owner-lane variant (P == 8, MSDA_LW_PRE): the tap arithmetic above is identical on the 8 / 16 lanes of a (query, head) group —
+    // ~45 of the ~100 VALU instructions per point.  Lane `sub` (< 8) does it ONCE for point `sub` of the level (its own 8-byte
+    // location: the group's 8 loads are one 64-byte segment instead of 8 broadcasts) and packs the corner-00 row index, the four
+    // corner masks and the +1 column / +1 row flags into one dword; the point loop fetches {packed, frac x, frac y, weight} of point
+    // p from lane p (4 lane reads) and goes straight to the row gathers.
+#define MSDA_LW_OWNER(l_, pk_, oax_, oay_, owg_)                                                          \
+    {                                                                                                     \
+      const int j = (l_) * 8 + (sub & 7);                                                                 \
+      const float2 xy = *(const float2*)(lp + 2 * j);                                                     \
+      owg_ = ap[j];                                                                                       \
+      const float x = xy.x * (float)Wl - 0.5f, y = xy.y * (float)Hl - 0.5f;                               \
+      const bool in = live && y > -1.f && x > -1.f && y < (float)Hl && x < (float)Wl;                     \
+      const float xc = fminf(fmaxf(x, -1.f), (float)Wl), yc = fminf(fmaxf(y, -1.f), (float)Hl);           \
+      const float xf = floorf(xc), yf = floorf(yc);                                                       \
+      const int x0 = (int)xf, y0 = (int)yf;                                                               \
+      oax_ = xc - xf; oay_ = yc - yf;                                                                     \
+      const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);                           \
+      const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);                           \
+      const bool k_xa = in && x0 >= 0, k_xb = in && x0 + 1 < Wl, k_ya = y0 >= 0, k_yb = y0 + 1 < Hl;      \
+      const int m = ((k_ya && k_xa) ? 1 : 0) | ((k_ya && k_xb) ? 2 : 0) | ((k_yb && k_xa) ? 4 : 0) | ((k_yb && k_xb) ? 8 : 0); \
+      pk_ = (mul24(ya, Wl) + xa) | (m << 26) | ((xb - xa) << 30) | ((yb - ya) << 31);                     \
+    }
+#define MSDA_LW_POINT_PRE(p_, pk_, oax_, oay_, owg_, sv_, sx_, sy_)                                       \
+    {                                                                                                     \
+      const int k = __shfl(pk_, (p_), G);                                                                 \
+      const float ax = __shfl(oax_, (p_), G), ay = __shfl(oay_, (p_), G), wgt = __shfl(owg_, (p_), G);    \
+      const float bx = 1.f - ax, by = 1.f - ay;                                                           \
+      const int i00 = k & 0x03ffffff, dx = (k >> 30) & 1;                                                 \
+      const int i10 = i00 + ((k >> 31) & Wl);                                                             \
+      const lw_raw_t r00 = *(const lw_raw_t*)(vl + mul24(i00, nh64));                                     \
+      const lw_raw_t r01 = *(const lw_raw_t*)(vl + mul24(i00 + dx, nh64));                                \
+      const lw_raw_t r10 = *(const lw_raw_t*)(vl + mul24(i10, nh64));                                     \
+      const lw_raw_t r11 = *(const lw_raw_t*)(vl + mul24(i10 + dx, nh64));                                \
+      float d00 = RowDot<T>::dot(go, r00), d01 = RowDot<T>::dot(go, r01);                                 \
+      float d10 = RowDot<T>::dot(go, r10), d11 = RowDot<T>::dot(go, r11);                                 \
+      d00 = (k & (1 << 26)) ? d00 : 0.f; d01 = (k & (2 << 26)) ? d01 : 0.f;                               \
+      d10 = (k & (4 << 26)) ? d10 : 0.f; d11 = (k & (8 << 26)) ? d11 : 0.f;                               \
+      const float s_val = by * bx * d00 + by * ax * d01 + ay * bx * d10 + ay * ax * d11;                  \
+      const float s_dx = by * (d01 - d00) + ay * (d11 - d10);                                             \
+      const float s_dy = bx * (d10 - d00) + ax * (d11 - d01);                                             \
+      sv_ = s_val; sx_ = s_dx * (wgt * (float)Wl); sy_ = s_dy * (wgt * (float)Hl);                        \
+    }
     float ka[4];                                      // EMIT: d_attw of point `sub` at each level (static indices: the branches below are uniform)
     for (int l = 0; l < L; ++l) {
       const int Hl = lv.H[l], Wl = lv.W[l];
@@ -310,8 +355,16 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
       if (P == 8) {
         // 24 partial sums per level, reduce-scattered over the lane group (24 -> 12 -> 6 -> 3 values per lane)
         float part[24];
+#if MSDA_LW_PRE
+        int pk;
+        float oax, oay, owg;
+        MSDA_LW_OWNER(l, pk, oax, oay, owg)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) MSDA_LW_POINT_PRE(p, pk, oax, oay, owg, part[p], part[8 + p], part[16 + p])
+#else
 #pragma unroll
         for (int p = 0; p < 8; ++p) MSDA_LW_POINT(l * 8 + p, part[p], part[8 + p], part[16 + p])
+#endif
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           const bool up = sub & (G / 2);
@@ -382,6 +435,8 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
       }
     }
 #undef MSDA_LW_POINT
+#undef MSDA_LW_OWNER
+#undef MSDA_LW_POINT_PRE
     if constexpr (EMIT) {
       // softmax backward over the (q, head) group's 32 points: lane sub < 8 holds d_attw of point `sub` of every level
       float aw[4], t = 0.f;
