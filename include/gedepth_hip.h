@@ -29,7 +29,8 @@ extern "C" {
 enum { GE_F32 = 0, GE_BF16 = 1 };
 enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
 
-/* Library / device identification: returns the ABI version (1). */
+/* Library / device identification: returns the ABI version (3: round 3 added the raw-projection deformable-attention entry points,
+ * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
