@@ -621,6 +621,85 @@ def bilinear_resize(x, size, align_corners=False):
     return _Bilinear.apply(x, Ho, Wo, bool(align_corners))
 
 
+# ------------------------------------------------------------------------ 3x3 convolution on MFMA (csrc/conv3x3.hip)
+def _conv3x3_launch(x, w_ohwi, bias, act, slope):
+    N, C, H, W = x.shape
+    Co = w_ohwi.shape[0]
+    y = torch.empty((N, Co, H, W), device=x.device, dtype=torch.bfloat16, memory_format=_CL)
+    flops = 2 * N * H * W * C * Co * 9
+    PROFILER.run(f'conv3x3[{N}x{C}->{Co} {H}x{W}{" +b" if bias is not None else ""}{" act" if act else ""}]',
+                 (x.numel() + y.numel() + w_ohwi.numel()) * 2, lambda: hip.check(hip.lib().ge_conv3x3_nhwc_fwd(
+                     _raw_ptr(x, 'x'), hip.ptr(w_ohwi, torch.bfloat16), hip.ptr(bias, _f32), _raw_ptr(y, 'y'), N, H, W, C, Co, int(act), float(slope),
+                     hip.GE_BF16, hip.stream()), 'ge_conv3x3_nhwc_fwd'), flops=flops)
+    return y
+
+
+class _Conv3x3(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 convolution (+ bias, + leaky-ReLU) on the hand-written MFMA kernel: forward AND data gradient (the same
+    kernel on the flipped / transposed weights); the weight gradient stays MIOpen's (``aten::convolution_backward`` with only that
+    output requested).  bf16 channels-last maps; the fp32 master weight is read through a bf16 copy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x = _cl(x.to(torch.bfloat16))
+        wb = weight.detach().to(torch.bfloat16)
+        if not wb.is_contiguous(memory_format=_CL):
+            wb = wb.contiguous(memory_format=_CL)
+        w_ohwi = wb.permute(0, 2, 3, 1)                                      # a view: the channels-last storage IS (O, H, W, I)
+        b32 = None if bias is None else _c(bias.detach().to(_f32))
+        y = _conv3x3_launch(x, w_ohwi, b32, act, slope)
+        ctx.save_for_backward(x, wb, y if act else None)
+        ctx.meta = (act, slope, bias is not None, weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb, y = ctx.saved_tensors
+        act, slope, has_bias, w_dtype, b_dtype = ctx.meta
+        N, Co, H, W = dy.shape
+        dy = _cl(dy.to(torch.bfloat16))
+        db = None
+        with torch.autocast('cuda', enabled=False):
+            if act:                                                             # d(pre-activation) and the bias gradient in one pass
+                dyp = torch.empty_like(dy)
+                dbf = torch.empty(Co, device=dy.device, dtype=_f32)
+                ws = torch.empty(int(hip.lib().ge_nhwc_workspace(Co, 1)), device=dy.device, dtype=torch.uint8)
+                PROFILER.run(f'bias_act_nhwc_bwd[{N}x{Co}x{H}x{W} bf16]', 3 * dy.numel() * 2, lambda: hip.check(hip.lib().ge_bias_act_nhwc_bwd(
+                    _raw_ptr(dy, 'dy'), _raw_ptr(y, 'y'), _raw_ptr(dyp, 'dx'), hip.ptr(dbf), hip.ptr(ws), N * H * W, Co, slope, hip.GE_BF16,
+                    hip.stream()), 'ge_bias_act_nhwc_bwd'))
+                dy = dyp
+                db = dbf if has_bias else None
+            elif has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy.permute(0, 2, 3, 1).reshape(N * H * W, Co))
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                wt = wb.permute(1, 2, 3, 0).flip(1, 2).contiguous()             # (I, 3, 3, O): w'[ci, r, s, co] = w[co, 2 - r, 2 - s, ci]
+                dx = _conv3x3_launch(dy, wt, None, 0, 1.0)
+            if ctx.needs_input_grad[1]:
+                dw = torch.ops.aten.convolution_backward(dy, x, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+                dw = dw.to(w_dtype)
+        return dx, dw, (None if db is None else db.to(b_dtype)), None, None
+
+
+def conv3x3_ok(conv, x):
+    """The MFMA convolution applies: plain 3x3 / stride 1 / pad 1 nn.Conv2d, bf16 execution (bf16 input or bf16 autocast), channel
+    counts the kernel and its data-gradient instance take (multiples of 32 both ways)."""
+    if 'conv3x3' in DISABLED or type(conv) is not torch.nn.Conv2d or not x.is_cuda or x.dim() != 4:
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    if conv.padding_mode != 'zeros' or conv.in_channels % 32 or conv.out_channels % 32:
+        return False
+    bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    # channels-last execution only (depth.models.utils.to_channels_last): an NCHW model keeps its layout end to end on the library path
+    return bf16 and _is_cl(x) and x.shape[0] * ((conv.out_channels + 63) // 64) <= 65535
+
+
+def conv3x3(conv, x, bias=None, act=False, slope=1.0):
+    """``act(conv(x) + bias)`` for a 3x3 nn.Conv2d module on the MFMA kernel (``conv3x3_ok`` must hold)."""
+    return _Conv3x3.apply(x, conv.weight, bias, bool(act), float(slope))
+
+
 # -------------------------------------------------------------- decoder glue: up-sample + concat, sum of up-sampled maps
 class _UpCat(torch.autograd.Function):
 

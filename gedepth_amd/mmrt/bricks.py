@@ -381,7 +381,14 @@ class ConvModule(nn.Module):
         slope = self._fused_slope() if x.is_cuda else None
         if slope is not None:
             return conv_bias_act(self.conv, x, slope)
-        x = self.conv(x)
+        if x.is_cuda and self.conv.bias is None:
+            from .. import kernels
+            if kernels.conv3x3_ok(self.conv, x):              # hand-written MFMA implicit GEMM (forward + data gradient)
+                x = kernels.conv3x3(self.conv, x)
+            else:
+                x = self.conv(x)
+        else:
+            x = self.conv(x)
         if x.is_cuda and self.with_norm and x.dtype in (torch.float32, torch.bfloat16):
             slope = self._fused_bn_slope()
             if slope is not None:                       # training-mode BatchNorm2d (+ ReLU): the fused HIP kernels
@@ -402,6 +409,8 @@ def conv_bias_act(conv, x, slope=1.0):
     bias-free convolution output (MIOpen has no fused epilogue for these shapes; ATen would launch a broadcast add
     and an activation kernel, and two more for their gradients)."""
     from .. import kernels
+    if kernels.conv3x3_ok(conv, x):                            # MFMA 3x3 convolution with the bias / activation in its epilogue
+        return kernels.conv3x3(conv, x, conv.bias, act=slope != 1.0, slope=slope)
     y = conv._conv_forward(x, conv.weight, None)
     if not (y.is_contiguous() or kernels._cl_ok(y)):           # dense NCHW or (vector-sized) channels-last both run in place
         y = y.contiguous()

@@ -351,6 +351,14 @@ int ge_upcat_nhwc_bwd(const void* d_out, void* d_coarse, int N, int Cu, int Hc, 
                       int dtype, void* stream);
 int ge_upsum_nhwc_fwd(const void* const* srcs, const int* hw, int nsrc, const void* fine, void* out, int N, int C, int H, int W,
                       int align_corners, int dtype, void* stream);
+
+/* 3x3 / stride 1 / pad 1 convolution on channels-last bf16 maps as an implicit GEMM on v_mfma_f32_32x32x16_bf16 (csrc/conv3x3.hip), with
+ * the bias + (Leaky)ReLU epilogue of mmcv's ConvModule: y (N,H,W,Cout) = act(conv(x (N,H,W,Cin), w (Cout,3,3,Cin)) + bias).  `w` is in the
+ * storage order of a channels-last conv weight (O, H, W, I); act = 0: none, 1: leaky-ReLU(slope) (slope 0 = ReLU); bias f32 or NULL.
+ * Cin % 32 == 0, Cout % 8 == 0, dtype GE_BF16.  The data gradient of the same layer is this call on d_y with the flipped / transposed
+ * weights w'[ci, r, s, co] = w[co, 2 - r, 2 - s, ci].  Reference call sites: decode_heads/densedepth_head.py:14-27, necks/hahi.py:140-165. */
+int ge_conv3x3_nhwc_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout, int act,
+                        float slope, int dtype, void* stream);
 /* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
 size_t ge_nhwc_workspace(int C, int K);
 

@@ -1474,3 +1474,41 @@ def test_upsum_matches_pe_trunk_composition(dev, dtype):
     close_scaled(fg.grad.float(), f64.grad, rel=tol, what='d fine')
     for a, b, s in zip(cg, c64, sizes):
         close_scaled(a.grad.float(), b.grad, rel=tol, what=f'd coarse {s}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('act', [False, True])
+@pytest.mark.parametrize('geom', [(2, 64, 64, 16, 40), (1, 160, 64, 13, 37), (2, 96, 96, 9, 33), (1, 288, 192, 22, 70), (1, 64, 128, 8, 32), (2, 32, 32, 3, 5)])
+def test_conv3x3_mfma_vs_conv2d(dev, geom, act):
+    """kernels.conv3x3 (ge_conv3x3_nhwc_fwd: implicit-GEMM 3x3 convolution on v_mfma_f32_32x32x16_bf16 with the bias + LeakyReLU epilogue;
+    its data gradient = the same kernel on flipped / transposed weights; weight gradient = the library's) against F.conv2d in float64 on the
+    same bf16-rounded operands: y, d_x, d_w, d_bias; tiles that hang over the right / bottom border, several 64-channel output tiles, a
+    partial one (96), maps smaller than one tile."""
+    from gedepth_amd import kernels
+    N, Ci, Co, H, W = geom
+    g = gen(51)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).bfloat16()
+    b = torch.randn(Co, generator=g) * 0.2
+    go = torch.randn(N, Co, H, W, generator=g).bfloat16()
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, b64, padding=1)
+    if act:
+        ref = F.leaky_relu(ref, 0.01)
+    ref.backward(go.double())
+    conv = torch.nn.Conv2d(Ci, Co, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        conv.weight.copy_(w.float())
+        conv.bias.copy_(b)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert kernels.conv3x3_ok(conv, xg)
+    kernels.PROFILER.enable()
+    y = kernels.conv3x3(conv, xg, conv.bias, act=act, slope=0.01)
+    y.backward(go.to(dev))
+    kernels.PROFILER.disable()
+    assert sum(r['name'].startswith('conv3x3[') for r in kernels.PROFILER.summary()) == 2        # forward and data gradient on the MFMA kernel
+    assert y.dtype == torch.bfloat16 and kernels._is_cl(y)
+    close_scaled(y.float(), ref, rel=1e-2, what='conv3x3 y')
+    close_scaled(xg.grad.float(), x64.grad, rel=1e-2, what='conv3x3 d_x')
+    close_scaled(conv.weight.grad.float(), w64.grad, rel=2e-2, what='conv3x3 d_w')
+    close_scaled(conv.bias.grad.float(), b64.grad, rel=2e-2, what='conv3x3 d_bias')
