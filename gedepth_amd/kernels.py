@@ -635,9 +635,9 @@ def _conv3x3_launch(x, w_ohwi, bias, act, slope):
 
 
 class _Conv3x3(torch.autograd.Function):
-    """3x3 / stride 1 / pad 1 convolution (+ bias, + leaky-ReLU) on the hand-written MFMA kernel: forward AND data gradient (the same
-    kernel on the flipped / transposed weights); the weight gradient stays MIOpen's (``aten::convolution_backward`` with only that
-    output requested).  bf16 channels-last maps; the fp32 master weight is read through a bf16 copy."""
+    """3x3 / stride 1 / pad 1 convolution (+ bias, + leaky-ReLU) on the hand-written MFMA kernels: forward, data gradient (the same
+    kernel on the flipped / transposed weights) and weight gradient (csrc/conv3x3_wgrad.hip, fp32 accumulation).  bf16 channels-last
+    maps; the fp32 master weight is read through a bf16 copy."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, act, slope):
@@ -676,8 +676,20 @@ class _Conv3x3(torch.autograd.Function):
                 wt = wb.permute(1, 2, 3, 0).flip(1, 2).contiguous()             # (I, 3, 3, O): w'[ci, r, s, co] = w[co, 2 - r, 2 - s, ci]
                 dx = _conv3x3_launch(dy, wt, None, 0, 1.0)
             if ctx.needs_input_grad[1]:
-                dw = torch.ops.aten.convolution_backward(dy, x, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-                dw = dw.to(w_dtype)
+                Ci = x.shape[1]
+                # measured against MIOpen's wrw kernels (scratch/conv_time.py): the MFMA weight gradient wins where the pixel count is
+                # large and the output small (176 x 560 maps: 885 vs 1338 us for 576 -> 64), ties at 88 x 280, loses on the coarse levels
+                # (few pixel tiles per K split, many output blocks: atomics + zero fill) -> used from 4e5 pixels
+                if 'conv3x3_wgrad' not in DISABLED and w_dtype == _f32 and N * H * W >= 400000:
+                    # MFMA weight gradient, fp32 accumulation straight into an (O, H, W, I) tensor = a channels-last (O, I, 3, 3) gradient
+                    dw_ohwi = torch.zeros(Co, 3, 3, Ci, device=dy.device, dtype=_f32)
+                    PROFILER.run(f'conv3x3_wgrad[{N}x{Ci}->{Co} {H}x{W}]', (x.numel() + dy.numel()) * 2 + dw_ohwi.numel() * 4, lambda: hip.check(
+                        hip.lib().ge_conv3x3_nhwc_wgrad(_raw_ptr(x, 'x'), _raw_ptr(dy, 'dy'), hip.ptr(dw_ohwi), N, H, W, Ci, Co, hip.GE_BF16, hip.stream()),
+                        'ge_conv3x3_nhwc_wgrad'), flops=2 * N * H * W * Ci * Co * 9)
+                    dw = dw_ohwi.permute(0, 3, 1, 2)
+                else:
+                    dw = torch.ops.aten.convolution_backward(dy, x, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+                    dw = dw.to(w_dtype)
         return dx, dw, (None if db is None else db.to(b_dtype)), None, None
 
 

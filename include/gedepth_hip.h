@@ -359,6 +359,10 @@ int ge_upsum_nhwc_fwd(const void* const* srcs, const int* hw, int nsrc, const vo
  * weights w'[ci, r, s, co] = w[co, 2 - r, 2 - s, ci].  Reference call sites: decode_heads/densedepth_head.py:14-27, necks/hahi.py:140-165. */
 int ge_conv3x3_nhwc_fwd(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout, int act,
                         float slope, int dtype, void* stream);
+/* Weight gradient of the same layer on the matrix cores (csrc/conv3x3_wgrad.hip): dw (Cout, 3, 3, Cin) fp32 [(O, H, W, I) order] +=
+ * sum over pixels of dy (N,H,W,Cout) x shifted x (N,H,W,Cin); both bf16 channels-last; the CALLER zero-fills dw (partial sums of the
+ * K-split workgroups meet through fp32 atomics).  Cin % 32 == 0, Cout % 8 == 0. */
+int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
 /* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
 size_t ge_nhwc_workspace(int C, int K);
 

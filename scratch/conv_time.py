@@ -36,4 +36,16 @@ for N, H, W, Ci, Co in shapes:
     t_ours = timeit(lambda: ours(x, w_ohwi, b, 1, 0.01))
     t_lib = timeit(lambda: F.conv2d(x, w, None, padding=1))
     fl = 2 * N * H * W * Ci * Co * 9
+    go = torch.randn(N, Co, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    def wg_ours():
+        dw = torch.zeros(Co, 3, 3, Ci, device=dev, dtype=torch.float32)
+        hip.check(hip.lib().ge_conv3x3_nhwc_wgrad(x.data_ptr(), go.data_ptr(), dw.data_ptr(), N, H, W, Ci, Co, 1, hip.stream()), 'wgrad')
+        return dw
+    def wg_lib():
+        return torch.ops.aten.convolution_backward(go, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+    def dg_lib():
+        return torch.ops.aten.convolution_backward(go, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    dw_ref = torch.ops.aten.convolution_backward(go.float(), x.float(), w.float(), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+    werr = (wg_ours().permute(0, 3, 1, 2) - dw_ref).abs().max().item() / dw_ref.abs().max().item()
+    print(f'     wgrad rel err {werr:.1e} | ours {timeit(wg_ours):7.1f} us | MIOpen wgrad {timeit(wg_lib):7.1f} us | MIOpen dgrad {timeit(dg_lib):7.1f} us', flush=True)
     print(f'3x3 {Ci:4d}->{Co:3d} @{H}x{W} N{N}: rel err {err:.1e} | ours {t_ours:7.1f} us ({fl / t_ours / 1e6:6.0f} TF/s) | MIOpen {t_lib:7.1f} us ({fl / t_lib / 1e6:6.0f} TF/s)', flush=True)

@@ -1481,7 +1481,7 @@ def test_upsum_matches_pe_trunk_composition(dev, dtype):
 @pytest.mark.parametrize('geom', [(2, 64, 64, 16, 40), (1, 160, 64, 13, 37), (2, 96, 96, 9, 33), (1, 288, 192, 22, 70), (1, 64, 128, 8, 32), (2, 32, 32, 3, 5)])
 def test_conv3x3_mfma_vs_conv2d(dev, geom, act):
     """kernels.conv3x3 (ge_conv3x3_nhwc_fwd: implicit-GEMM 3x3 convolution on v_mfma_f32_32x32x16_bf16 with the bias + LeakyReLU epilogue;
-    its data gradient = the same kernel on flipped / transposed weights; weight gradient = the library's) against F.conv2d in float64 on the
+    its data gradient = the same kernel on flipped / transposed weights; weight gradient = ge_conv3x3_nhwc_wgrad, transposing LDS reads) against F.conv2d in float64 on the
     same bf16-rounded operands: y, d_x, d_w, d_bias; tiles that hang over the right / bottom border, several 64-channel output tiles, a
     partial one (96), maps smaller than one tile."""
     from gedepth_amd import kernels
@@ -1506,7 +1506,15 @@ def test_conv3x3_mfma_vs_conv2d(dev, geom, act):
     y = kernels.conv3x3(conv, xg, conv.bias, act=act, slope=0.01)
     y.backward(go.to(dev))
     kernels.PROFILER.disable()
-    assert sum(r['name'].startswith('conv3x3[') for r in kernels.PROFILER.summary()) == 2        # forward and data gradient on the MFMA kernel
+    names = [r['name'] for r in kernels.PROFILER.summary()]
+    assert sum(n.startswith('conv3x3[') for n in names) == 2                                      # forward and data gradient on the MFMA kernel
+    # the MFMA weight gradient is used from 4e5 pixels (where it beats MIOpen); checked here directly at every geometry
+    dw = torch.zeros(Co, 3, 3, Ci, device=dev)
+    from gedepth_amd import hip
+    xb, gb = xg.detach(), go.to(dev).contiguous(memory_format=torch.channels_last)
+    dyp = gb if not act else (gb.float() * torch.where(y.detach().float() > 0, 1.0, 0.01)).bfloat16().contiguous(memory_format=torch.channels_last)
+    hip.check(hip.lib().ge_conv3x3_nhwc_wgrad(xb.data_ptr(), dyp.data_ptr(), dw.data_ptr(), N, H, W, Ci, Co, 1, hip.stream()), 'ge_conv3x3_nhwc_wgrad')
+    close_scaled(dw.permute(0, 3, 1, 2), w64.grad, rel=2e-2, what='ge_conv3x3_nhwc_wgrad')
     assert y.dtype == torch.bfloat16 and kernels._is_cl(y)
     close_scaled(y.float(), ref, rel=1e-2, what='conv3x3 y')
     close_scaled(xg.grad.float(), x64.grad, rel=1e-2, what='conv3x3 d_x')
