@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_nhwc_k(const bf16_t* __restric
         float v = acc[mb][nb][r] + bv;
         if (act) v = v > 0.f ? v : v * slope;
         const int px = (r & 3) + 8 * (r >> 2) + 4 * kg;
-        ot[(mb * 32 + px) * 72 + co] = f2bf(v);
+        ot[(mb * 32 + px) * 72 + co] = __builtin_bit_cast(bf16_t, (__bf16)v);        // v_cvt_pk_bf16_f32 (round-to-nearest-even, like f2bf)
       }
     }
   __builtin_amdgcn_wave_barrier();
