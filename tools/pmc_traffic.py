@@ -24,7 +24,7 @@ from collections import defaultdict
 
 OURS = ('msda_', 'window_attn', 'bilinear_', 'bias_act_', 'tokens_from_map', 'map_from_tokens', 'ground_', 'depth_fuse',
         'silog_', 'sumsq_k', 'adamw_k', 'pe_channels', 'slope_class', 'upcat_', 'upsum_', 'bias_gelu', 'bn_', 'colsum_k', 'concat_rows',
-        'slice_rows', 'add_rows', 'layernorm_', 'residual_', 'scale_rows')
+        'slice_rows', 'add_rows', 'layernorm_', 'residual_', 'scale_rows', 'conv3x3_', 'mw_prepare', 'aug_')
 
 
 def short(name):
