@@ -320,7 +320,7 @@ def main():
         if prof:
             # the MSDA backward is several kernels behind one entry point: rank its kernels individually (timed by HIP events
             # inside the library), so that `roofline` is about ONE kernel whose name rocprofv3 reports too
-            single = [r for r in prof if not (stages and r['name'].startswith('msda_bwd['))] + stages
+            single = [r for r in prof if not (stages and r['name'].startswith(('msda_bwd[', 'msda_bwd_raw[')))] + stages
             dom = max(single, key=lambda r: r['total_ms'])
             gbs = dom['bytes_per_launch'] / (dom['avg_us'] * 1e-6) / 1e9
             res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,

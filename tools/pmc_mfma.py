@@ -8,7 +8,10 @@ SQ_INSTS_VALU_MFMA_MOPS_BF16 counts bf16 MFMA work in units of 512 FLOP (MI355X_
 derived-metric table, so the raw counter is reported together with the unit check below).  Unit check: window_attn_fwd_mfma_k
 issues exactly 16 v_mfma_f32_32x32x16_bf16 (32768 FLOP each) per (window, head) workgroup, so counter * 512 / (16 * 32768 * grid)
 must be 1; the measured ratio is stored as `calibration`.  MFMA utilisation of a kernel = its MFMA FLOP / (duration * 2.5 PFLOP/s),
-with the duration from GRBM_GUI_ACTIVE (cycles the GPU was busy with the dispatch) at the clock the same record implies.
+with the duration from GRBM_GUI_ACTIVE.  That counter is SUMMED over the 8 XCDs (each has its own GRBM): against rocprofv3's
+kernel-trace durations of the same kernels it reads 17.4 - 17.9 cycles per ns for every kernel longer than 100 us = 8 x 2.2 GHz, so
+the per-dispatch busy time is counter / 8 / clock.  Short kernels read higher (fixed per-dispatch overhead of the counter mode).
+`--from-json` recomputes the derived columns of an existing output (the raw counters are kept in it).
 """
 import argparse
 import csv
@@ -26,9 +29,14 @@ def short(name):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--dir', required=True)
+    ap.add_argument('--dir', default=None)
     ap.add_argument('--out', default='profiles/r3_mfma_counters.json')
+    ap.add_argument('--from-json', default=None)
     a = ap.parse_args()
+    if a.from_json:
+        old = json.load(open(a.from_json))
+        finish(old['kernels'], old.get('calibration'), a.out)
+        return
     files = glob.glob(os.path.join(a.dir, '**', '*counter_collection.csv'), recursive=True)
     if not files:
         raise SystemExit(f'no *counter_collection.csv under {a.dir}')
@@ -63,10 +71,22 @@ def main():
             got = r['mfma_gflop_per_dispatch'] * r['dispatches']
             cal = dict(kernel=r['kernel'], workgroups=wgs, expected_gflop=expect, counted_gflop=got, ratio=got / expect if expect else None)
             break
+    finish(rows, cal, a.out)
+
+
+XCDS = 8
+CLOCK_HZ = 2.4e9           # peak engine clock: the 2.5 PFLOP/s dense bf16 figure is quoted at it
+
+
+def finish(rows, cal, out_path):
+    class A:
+        out = out_path
+    a = A()
     for r in rows:
-        cyc = r['grbm_gui_active_per_dispatch']
-        # 2.5 PFLOP/s at 2.4 GHz = 1041.7 kFLOP per GPU cycle
-        r['mfma_util_vs_2p5pf'] = round(r['mfma_gflop_per_dispatch'] * 1e9 / (cyc * 2.5e15 / 2.4e9), 4) if cyc else None
+        cyc = r['grbm_gui_active_per_dispatch'] / XCDS
+        r['busy_cycles_per_xcd'] = round(cyc, 1)
+        # 2.5 PFLOP/s at 2.4 GHz = 1041.7 kFLOP per GPU cycle: utilisation in MFMA-issue cycles, independent of the clock the run held
+        r['mfma_util_vs_2p5pf'] = round(r['mfma_gflop_per_dispatch'] * 1e9 / (cyc * 2.5e15 / CLOCK_HZ), 4) if cyc else None
     out = dict(source='rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE of bench.py --steps 1', unit='counter x 512 FLOP',
                calibration=cal, kernels=rows)
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
