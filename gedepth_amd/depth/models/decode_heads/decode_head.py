@@ -12,6 +12,7 @@ from abc import ABCMeta, abstractmethod
 import torch
 import torch.nn as nn
 
+from .... import kernels
 from ....kernels import depth_fuse
 from ....mmrt.bricks import BaseModule
 from ...ops import resize
@@ -61,7 +62,10 @@ class DepthBaseDecodeHead(BaseModule, metaclass=ABCMeta):
         return self.forward(inputs, img_metas, pe_mask, y)[0]
 
     def depth_pred(self, feat, pe, depth_y):
-        c = self.conv_depth(feat).float()
+        if feat.is_cuda and kernels.conv3x3_c1_ok(self.conv_depth, feat):   # 64 -> 1: streaming HIP kernel, fp32 result directly
+            c = kernels.conv3x3_c1(self.conv_depth, feat, out_fp32=True)
+        else:
+            c = self.conv_depth(feat).float()
         if pe is None:
             return torch.relu(c) + self.min_depth, depth_y
         if not self.align_corners:

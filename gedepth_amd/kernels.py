@@ -712,6 +712,61 @@ def conv3x3(conv, x, bias=None, act=False, slope=1.0):
     return _Conv3x3.apply(x, conv.weight, bias, bool(act), float(slope))
 
 
+class _Conv3x3C1(torch.autograd.Function):
+    """3x3 / stride 1 / pad 1 convolution to ONE output channel (+ bias) on the streaming kernels of csrc/conv3x3_c1.hip: forward, and a
+    single backward pass for dx, dw and db.  The fp32 master weight is read directly (rounded to bf16 in the kernel, as autocast's cast
+    does): no cast, flip or zero-fill kernels around it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_fp32):
+        x = _cl(x.to(torch.bfloat16))
+        N, C, H, W = x.shape
+        w = weight.detach().permute(0, 2, 3, 1)                              # (1, 3, 3, I): a view of a channels-last weight
+        if not w.is_contiguous():
+            w = w.contiguous()
+        b = None if bias is None else bias.detach()
+        y = torch.empty((N, 1, H, W), device=x.device, dtype=_f32 if out_fp32 else torch.bfloat16)
+        PROFILER.run(f'conv3x3_c1[{N}x{C}->1 {H}x{W}]', x.numel() * 2 + y.numel() * y.element_size(), lambda: hip.check(hip.lib().ge_conv3x3_c1_fwd(
+            _raw_ptr(x, 'x'), hip.ptr(w, _f32), hip.ptr(b, _f32), hip.ptr(y), N, H, W, C, hip.GE_F32 if out_fp32 else hip.GE_BF16, hip.stream()),
+            'ge_conv3x3_c1_fwd'))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, C, H, W = x.shape
+        if dy.dtype not in (_f32, torch.bfloat16):
+            dy = dy.float()
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dw = torch.empty((1, 3, 3, C), device=x.device, dtype=_f32)
+        db = torch.empty(1, device=x.device, dtype=_f32) if ctx.has_bias else None
+        PROFILER.run(f'conv3x3_c1_bwd[{N}x{C}->1 {H}x{W}]', 2 * x.numel() * 2 + dy.numel() * dy.element_size(), lambda: hip.check(hip.lib().ge_conv3x3_c1_bwd(
+            _raw_ptr(x, 'x'), hip.ptr(dy), hip.ptr(w, _f32), _raw_ptr(dx, 'dx'), hip.ptr(dw), hip.ptr(db, _f32), N, H, W, C,
+            hip.GE_F32 if dy.dtype == _f32 else hip.GE_BF16, hip.stream()), 'ge_conv3x3_c1_bwd'))
+        return dx, dw.permute(0, 3, 1, 2), db, None
+
+
+def conv3x3_c1_ok(conv, x):
+    """The one-output-channel streaming convolution applies (3x3 / s1 / p1, bf16 channels-last execution, fp32 master weights)."""
+    if 'conv3x3_c1' in DISABLED or type(conv) is not torch.nn.Conv2d or not x.is_cuda or x.dim() != 4 or conv.out_channels != 1:
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    if conv.padding_mode != 'zeros' or conv.in_channels % 8 or conv.in_channels > 1024 or conv.weight.dtype != _f32:
+        return False
+    bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
+    return bf16 and _is_cl(x)
+
+
+def conv3x3_c1(conv, x, out_fp32=False):
+    """``conv(x)`` (bias included) for a 3x3 nn.Conv2d with one output channel (``conv3x3_c1_ok`` must hold); ``out_fp32``: the result in
+    fp32 instead of the autocast dtype (for a consumer that would cast it up anyway)."""
+    return _Conv3x3C1.apply(x, conv.weight, conv.bias, bool(out_fp32))
+
+
 # -------------------------------------------------------------- decoder glue: up-sample + concat, sum of up-sampled maps
 class _UpCat(torch.autograd.Function):
 

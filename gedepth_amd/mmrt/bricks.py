@@ -411,6 +411,8 @@ def conv_bias_act(conv, x, slope=1.0):
     from .. import kernels
     if kernels.conv3x3_ok(conv, x):                            # MFMA 3x3 convolution with the bias / activation in its epilogue
         return kernels.conv3x3(conv, x, conv.bias, act=slope != 1.0, slope=slope)
+    if slope == 1.0 and kernels.conv3x3_c1_ok(conv, x):        # one output channel: streaming kernel, one backward pass for dx / dw / db
+        return kernels.conv3x3_c1(conv, x)
     y = conv._conv_forward(x, conv.weight, None)
     if not (y.is_contiguous() or kernels._cl_ok(y)):           # dense NCHW or (vector-sized) channels-last both run in place
         y = y.contiguous()

@@ -363,6 +363,15 @@ int ge_conv3x3_nhwc_fwd(const void* x, const void* w, const float* bias, void* y
  * sum over pixels of dy (N,H,W,Cout) x shifted x (N,H,W,Cin); both bf16 channels-last; the CALLER zero-fills dw (partial sums of the
  * K-split workgroups meet through fp32 atomics).  Cin % 32 == 0, Cout % 8 == 0. */
 int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* The same layer with ONE output channel (csrc/conv3x3_c1.hip): the depth regressor `conv_depth` (reference
+ * depth/models/decode_heads/decode_head.py: nn.Conv2d(channels, 1, 3, padding=1)) and `convfinal` of the ground-attention neck
+ * (necks/pemask_neck.py:36-42): a streaming reduction on the vector pipe (v_dot2c_f32_bf16), not a GEMM with N = 1.
+ * fwd: y (N,H,W) [out_dtype GE_BF16 | GE_F32] = bias[0] + conv(x (N,H,W,Cin) bf16, w (1,3,3,Cin) f32 rounded to bf16 as autocast casts it).
+ * bwd: ONE pass gives dx (N,H,W,Cin) bf16, dw (1,3,3,Cin) f32 and db (1) f32 (NULL: skipped) from dy (N,H,W) [dy_dtype]; dw / db are
+ * zero-filled by the call.  Cin % 8 == 0, Cin <= 1024. */
+int ge_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin, int out_dtype, void* stream);
+int ge_conv3x3_c1_bwd(const void* x, const void* dy, const float* w, void* dx, float* dw, float* db, int N, int H, int W, int Cin,
+                      int dy_dtype, void* stream);
 /* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
 size_t ge_nhwc_workspace(int C, int K);
 

@@ -1520,3 +1520,41 @@ def test_conv3x3_mfma_vs_conv2d(dev, geom, act):
     close_scaled(xg.grad.float(), x64.grad, rel=1e-2, what='conv3x3 d_x')
     close_scaled(conv.weight.grad.float(), w64.grad, rel=2e-2, what='conv3x3 d_w')
     close_scaled(conv.bias.grad.float(), b64.grad, rel=2e-2, what='conv3x3 d_bias')
+
+
+@pytest.mark.parametrize('geom', [(8, 64, 176, 560), (2, 64, 13, 37), (1, 72, 9, 5), (3, 128, 1, 1), (1, 8, 40, 33)])
+@pytest.mark.parametrize('out_fp32', [False, True])
+def test_conv3x3_one_output_channel_vs_conv2d(dev, geom, out_fp32):
+    """kernels.conv3x3_c1 (ge_conv3x3_c1_fwd / _bwd: the 64 -> 1 depth regressor and ground-attention head as a streaming reduction;
+    ONE backward pass for d_x, d_w, d_bias) against F.conv2d in float64 on the same bf16-rounded operands: the bench shape, maps smaller
+    than a wave's 8 pixels, channel counts that are not a multiple of 64 (72: the last 8-lane step is partly masked; 128: two steps)."""
+    from gedepth_amd import kernels
+    N, Ci, H, W = geom
+    g = gen(52)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16()
+    w = (torch.randn(1, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).bfloat16()
+    b = torch.randn(1, generator=g) * 0.2
+    go = torch.randn(N, 1, H, W, generator=g)
+    if not out_fp32:
+        go = go.bfloat16()
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, b64, padding=1)
+    ref.backward(go.double())
+    conv = torch.nn.Conv2d(Ci, 1, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        conv.weight.copy_(w.float())
+        conv.bias.copy_(b)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert kernels.conv3x3_c1_ok(conv, xg)
+    kernels.PROFILER.enable()
+    y = kernels.conv3x3_c1(conv, xg, out_fp32=out_fp32)
+    y.backward(go.to(dev))
+    kernels.PROFILER.disable()
+    names = [r['name'] for r in kernels.PROFILER.summary()]
+    assert any(n.startswith('conv3x3_c1[') for n in names) and any(n.startswith('conv3x3_c1_bwd[') for n in names)
+    assert y.dtype == (torch.float32 if out_fp32 else torch.bfloat16) and y.shape == (N, 1, H, W)
+    close_scaled(y.float(), ref, rel=1e-2 if not out_fp32 else 2e-5, what='conv3x3_c1 y')
+    close_scaled(xg.grad.float(), x64.grad, rel=1e-2, what='conv3x3_c1 d_x')
+    assert conv.weight.grad.shape == (1, Ci, 3, 3)
+    close_scaled(conv.weight.grad.float(), w64.grad, rel=1e-4, what='conv3x3_c1 d_w')
+    close_scaled(conv.bias.grad.float(), b64.grad, rel=1e-4, what='conv3x3_c1 d_bias')
