@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_k(const TY* __restrict__ dy
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, TX* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C,
-                                                       int use_lds) {
+                                                       int use_lds, const TX* __restrict__ dres) {
   constexpr int RPB = 256 / GS;
   extern __shared__ float red[];                       // [RPB][2][C] when use_lds (column sums across the row groups)
   const int sub = threadIdx.x % GS, rg = threadIdx.x / GS;
@@ -136,6 +136,12 @@ __global__ void __launch_bounds__(256) layernorm_bwd_k(const TY* __restrict__ dy
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = rs * (g[j][k] - m1 - xh[j][k] * m2);
+        if (dres) {                                      // the gradient that reached x through the residual branch: summed here, not by autograd
+          float q[4];
+          Q4<TX>::ld(dres + row * C + c, q);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] += q[k];
+        }
         Q4<TX>::st(dp + c, o);
       }
     }
@@ -207,7 +213,7 @@ static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, v
 }
 template <typename TX, typename TY>
 static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                         float* dgamma, float* dbeta, long rows, int C, hipStream_t s) {
+                         float* dgamma, float* dbeta, long rows, int C, hipStream_t s, const void* dres = nullptr) {
   LnPlan pl;
   if (!ln_plan(C, pl)) return GE_ERR_UNSUPPORTED;
   const int rpb = 256 / pl.gs;
@@ -215,7 +221,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   size_t smem = (size_t)rpb * 2 * C * sizeof(float);
   const int use_lds = smem <= 60 * 1024;                               // else: per-lane column atomics (only LN(3072), few rows)
   if (!use_lds) smem = 0;
-#define LN_B(GS_, N_) layernorm_bwd_k<TX, TY, GS_, N_><<<blocks, 256, smem, s>>>((const TY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, C, use_lds)
+#define LN_B(GS_, N_) layernorm_bwd_k<TX, TY, GS_, N_><<<blocks, 256, smem, s>>>((const TY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, C, use_lds, (const TX*)dres)
 #define LN_B16(N_) LN_B(16, N_)
 #define LN_B32(N_) LN_B(32, N_)
 #define LN_B64(N_) LN_B(64, N_)
@@ -251,6 +257,20 @@ extern "C" int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int 
   if (x_dtype == GE_F32 && y_dtype == GE_BF16) return ln_bwd_launch<float, bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s);
   if (x_dtype == GE_BF16 && y_dtype == GE_BF16) return ln_bwd_launch<bf16_t, bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s);
   if (x_dtype == GE_BF16 && y_dtype == GE_F32) return ln_bwd_launch<bf16_t, float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s);
+  return GE_ERR_UNSUPPORTED;
+}
+
+// ge_layernorm_bwd with the residual gradient folded in: dx = LN'(dy) + dres (dres in x's dtype, may be NULL).  In a pre-norm block
+// x feeds both the LayerNorm and the skip connection; autograd would add the two gradients in a separate pass over the token tensor.
+extern "C" int ge_layernorm_bwd_res(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || C <= 0) return GE_ERR_BAD_ARG;
+  if (rows == 0) return GE_OK;
+  hipStream_t s = ge_stream(stream);
+  if (x_dtype == GE_F32 && y_dtype == GE_F32) return ln_bwd_launch<float, float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
+  if (x_dtype == GE_F32 && y_dtype == GE_BF16) return ln_bwd_launch<float, bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
+  if (x_dtype == GE_BF16 && y_dtype == GE_BF16) return ln_bwd_launch<bf16_t, bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
+  if (x_dtype == GE_BF16 && y_dtype == GE_F32) return ln_bwd_launch<bf16_t, float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
   return GE_ERR_UNSUPPORTED;
 }
 

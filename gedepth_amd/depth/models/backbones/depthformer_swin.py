@@ -108,6 +108,12 @@ class ShiftWindowMSA(BaseModule):
         return self.drop.residual(identity, out) if hasattr(self.drop, 'residual') else identity + self.drop(out)
 
 
+def _norm_with_skip(norm, x):
+    """(norm(x), x for the skip connection): the fused pair when the norm layer offers it (mmrt.bricks.LayerNorm.forward_with_skip)."""
+    f = getattr(norm, 'forward_with_skip', None)
+    return f(x) if f is not None else (norm(x), x)
+
+
 class SwinBlock(BaseModule):
     """x + DropPath(attn(LN x)); x + DropPath(FFN(LN x))  (reference :396-472)."""
 
@@ -126,8 +132,10 @@ class SwinBlock(BaseModule):
                        add_identity=True, init_cfg=None)
 
     def forward(self, x, hw_shape):
-        x = self.attn(self.norm1(x), hw_shape, identity=x)
-        return self.ffn(self.norm2(x), identity=x)
+        y, x = _norm_with_skip(self.norm1, x)
+        x = self.attn(y, hw_shape, identity=x)
+        y, x = _norm_with_skip(self.norm2, x)
+        return self.ffn(y, identity=x)
 
 
 class SwinBlockSequence(BaseModule):

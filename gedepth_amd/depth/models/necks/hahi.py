@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ....kernels import concat_tokens_map, ms_deform_attn_raw, tokens_from_map
+from ....kernels import add_rows, concat_tokens_map, ms_deform_attn_raw, residual_dropout, tokens_from_map
 from ....mmrt import bricks
 from ....mmrt.bricks import BaseModule, ConvModule, build_positional_encoding, xavier_init
 from ..builder import ATTENTION, NECKS
@@ -86,12 +86,17 @@ class MultiScaleDeformableAttention(BaseModule):
         if identity is None:
             identity = query                      # BEFORE the positional embedding is added
         if query_pos is not None:
-            query = query + query_pos.to(query.dtype)
+            if query_pos.dim() == 3 and query_pos.shape[0] == 1 and query_pos.dtype == torch.float32 and query.dim() == 3 and self.batch_first:
+                query = add_rows(query, query_pos[0])        # one pass; no (B, N, C) copy of the broadcast embedding
+            else:
+                query = query + query_pos.to(query.dtype)
         if not self.batch_first:
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         out = self._attend(query, value, reference_points, spatial_shapes, key_padding_mask, query_shapes)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
+        if self.training and self.dropout.p > 0 and out.is_cuda and out.dim() == 3 and self.batch_first:
+            return residual_dropout(identity, out, self.dropout.p)
         return self.dropout(out) + identity
 
     def forward_map(self, fmap, pos_map, value, reference_points, spatial_shapes, concat_with):
@@ -176,7 +181,7 @@ class HAHIHeteroNeck(BaseModule):
             poss.append(pos + self.level_embed[i].view(1, 1, -1))
             srcs.append(self.trans_proj[i](ft).flatten(2).transpose(1, 2))
         src_flatten = torch.cat(srcs, 1)
-        pos_flatten = torch.cat(poss, 1).expand(bs, -1, -1)
+        pos_flatten = torch.cat(poss, 1)                      # (1, N, C) fp32: broadcast over the batch inside the add
         if self.self_att:
             ref = self._pixel_centres(shapes, dev).expand(bs, -1, -1, -1)
             src = self.self_attn(src_flatten, value=None, identity=None, query_pos=pos_flatten,

@@ -460,7 +460,56 @@ class _AddRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d):
-        return d, None
+        d_pos = None
+        if ctx.needs_input_grad[1]:                         # rows that carry a Parameter (HAHI's level embedding): batch sum in fp32
+            d_pos = d.sum(0, dtype=_f32)
+        return d, d_pos
+
+
+def add_rows(tokens, rows):
+    """tokens (B,N,C) + rows (N,C) fp32 broadcast over the batch, one pass and one rounding; gradient to both."""
+    vn = 8 if tokens.dtype == torch.bfloat16 else 4
+    if tokens.is_cuda and tokens.dtype in (_f32, torch.bfloat16) and tokens.shape[2] % vn == 0 and rows.dtype == _f32:
+        return _AddRows.apply(tokens, _c(rows))
+    return tokens + rows.to(tokens.dtype)
+
+
+class _ResidualDropout(torch.autograd.Function):
+    """``identity + dropout(tokens)`` over token rows in one pass (the concat-rows kernel with an empty second part), backward: the mask is
+    recomputed from the seed (ge_slice_rows_drop) — replaces native_dropout + add and native_dropout_backward."""
+
+    @staticmethod
+    def forward(ctx, tok, identity, p, seed):
+        tok = _rows(tok)
+        B, N, C = tok.shape
+        res = _c(identity.to(tok.dtype))
+        out = torch.empty(B, N, C, device=tok.device, dtype=tok.dtype)
+        PROFILER.run(f'residual_dropout[{B}x{N}x{C} {_tag(tok)}]', 3 * tok.numel() * _es(tok), lambda: hip.check(hip.lib().ge_concat_rows_fwd(
+            _raw_ptr(tok, 'tokens'), N, tok.stride(0), _raw_ptr(res, 'identity'), None, _raw_ptr(out, 'out'), B * N, C, 0, 1, p, seed,
+            hip.dtype_code(tok), hip.stream()), 'ge_concat_rows_fwd'))
+        ctx.meta = (B, N, C, p, seed, identity.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        B, N, C, p, seed, id_dtype = ctx.meta
+        d_out = _c(d_out)
+        d_tok = torch.empty_like(d_out)
+        PROFILER.run(f'slice_rows_drop[{B}x{N}x{C} {_tag(d_out)}]', 2 * d_tok.numel() * _es(d_out), lambda: hip.check(
+            hip.lib().ge_slice_rows_drop(_raw_ptr(d_out, 'd_out'), hip.ptr(d_tok), B * N, C, C, 0, p, seed, hip.dtype_code(d_out), hip.stream()),
+            'ge_slice_rows_drop'))
+        return d_tok, d_out.to(id_dtype), None, None
+
+
+def residual_dropout(identity, tokens, p, seed=None):
+    """``identity + F.dropout(tokens, p)`` for token matrices (B,N,C) in training mode (p > 0)."""
+    vn = 8 if tokens.dtype == torch.bfloat16 else 4
+    if not (tokens.is_cuda and tokens.dim() == 3 and tokens.dtype in (_f32, torch.bfloat16) and tokens.shape[2] % vn == 0 and identity.shape == tokens.shape
+            and 0.0 < p < 1.0):
+        return identity + torch.nn.functional.dropout(tokens, p, True)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # host generator: follows torch.manual_seed, no device sync
+    return _ResidualDropout.apply(tokens, identity, float(p), int(seed))
 
 
 _POS_ROWS = {}
@@ -642,7 +691,8 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, slope):
         x = _cl(x.to(torch.bfloat16))
-        wb = weight.detach().to(torch.bfloat16)
+        from .mmrt.optim import lowp
+        wb = lowp(weight.detach(), torch.bfloat16)                             # the optimizer's bf16 shadow when current: no cast kernel
         if not wb.is_contiguous(memory_format=_CL):
             wb = wb.contiguous(memory_format=_CL)
         w_ohwi = wb.permute(0, 2, 3, 1)                                      # a view: the channels-last storage IS (O, H, W, I)
@@ -710,6 +760,41 @@ def conv3x3_ok(conv, x):
 def conv3x3(conv, x, bias=None, act=False, slope=1.0):
     """``act(conv(x) + bias)`` for a 3x3 nn.Conv2d module on the MFMA kernel (``conv3x3_ok`` must hold)."""
     return _Conv3x3.apply(x, conv.weight, bias, bool(act), float(slope))
+
+
+class _ConvLib(torch.autograd.Function):
+    """Library (MIOpen / CK) convolution without bias under bf16 autocast, with the weight read from the optimizer's bf16 shadow arena
+    (mmrt.optim.lowp) instead of autocast's per-step cast kernel; backward = the library's data / weight gradients, the latter widened to
+    the master dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, dilation, groups):
+        from .mmrt.optim import lowp
+        dt = torch.get_autocast_dtype('cuda')
+        with torch.autocast('cuda', enabled=False):
+            xc, wc = x.to(dt), lowp(weight.detach(), dt)
+            y = torch.nn.functional.conv2d(xc, wc, None, stride, padding, dilation, groups)
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (stride, padding, dilation, groups, x.dtype, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        stride, padding, dilation, groups, x_dtype, w_dtype = ctx.meta
+        with torch.autocast('cuda', enabled=False):
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy.to(wc.dtype), xc, wc, None, stride, padding, dilation, False, (0, 0), groups,
+                                                            (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False))
+        return (None if dx is None else dx.to(x_dtype)), (None if dw is None else dw.to(w_dtype)), None, None, None, None
+
+
+def conv_lib(conv, x):
+    """``conv._conv_forward(x, conv.weight, None)`` (no bias) — through ``_ConvLib`` when bf16 autocast training applies, else unchanged."""
+    if (x.is_cuda and type(conv) is torch.nn.Conv2d and conv.padding_mode == 'zeros' and torch.is_grad_enabled() and conv.weight.requires_grad
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16 and conv.weight.dtype == _f32
+            and not isinstance(conv.padding, str) and 'conv_lib' not in DISABLED):
+        return _ConvLib.apply(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return conv._conv_forward(x, conv.weight, None)
 
 
 class _Conv3x3C1(torch.autograd.Function):
@@ -886,6 +971,54 @@ class _LayerNorm(torch.autograd.Function):
                                        hip.ptr(rstd), hip.ptr(dx), hip.ptr(dwb[0]), hip.ptr(dwb[1]), rows, C, hip.stream()),
             'ge_layernorm_bwd'))
         return dx, dwb[0], dwb[1], None, None
+
+
+class _LayerNormRes(torch.autograd.Function):
+    """``(LN(x), x)`` for a pre-norm residual block: the second output is x itself, routed through this node so that the gradient arriving
+    over the skip connection is added to LN'(dy) INSIDE the LayerNorm backward kernel (ge_layernorm_bwd_res) instead of by a separate
+    autograd add over the token tensor (24 per Swin-T step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        x = _c(x)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        w, b = _c(weight.detach().to(_f32)), _c(bias.detach().to(_f32))
+        y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+        mean = torch.empty(rows, device=x.device, dtype=_f32)
+        rstd = torch.empty(rows, device=x.device, dtype=_f32)
+        PROFILER.run(f'layernorm_fwd[{rows}x{C} {_tag(x)}->{_tag(y)}]', x.numel() * _es(x) + y.numel() * _es(y), lambda: hip.check(
+            hip.lib().ge_layernorm_fwd(hip.ptr(x, name='x'), hip.dtype_code(x), hip.ptr(w), hip.ptr(b), hip.ptr(y),
+                                       hip.dtype_code(y), hip.ptr(mean), hip.ptr(rstd), rows, C, eps, hip.stream()),
+            'ge_layernorm_fwd'))
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, w, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        if dy is None:                                                          # LN output unused: only the skip gradient
+            return dres, None, None, None, None
+        dy = _c(dy)
+        if dy.dtype not in (_f32, torch.bfloat16):
+            dy = dy.to(_f32)
+        if dres is not None:
+            dres = _c(dres.to(x.dtype))
+        dx = torch.empty_like(x)
+        dwb = torch.zeros(2, C, device=x.device, dtype=_f32)
+        PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}{" +res" if dres is not None else ""}]',
+                     (2 + (dres is not None)) * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
+            hip.lib().ge_layernorm_bwd_res(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
+                                           hip.ptr(rstd), hip.ptr(dres), hip.ptr(dx), hip.ptr(dwb[0]), hip.ptr(dwb[1]), rows, C, hip.stream()),
+            'ge_layernorm_bwd_res'))
+        return dx, dwb[0], dwb[1], None, None
+
+
+def layer_norm_res(x, weight, bias, eps=1e-5, out_dtype=None):
+    """-> (LayerNorm(x), x') with x' == x numerically: use x' for the skip connection of a pre-norm block (see _LayerNormRes)."""
+    return _LayerNormRes.apply(x, weight, bias, float(eps), out_dtype or x.dtype)
 
 
 _COLSUM_WS = {}

@@ -244,15 +244,30 @@ class LayerNorm(nn.LayerNorm):
     autocast would give (the patch-embed norm, whose output is the fp32 residual stream of stage 0)."""
     autocast_out = True
 
+    def _hip_ok(self, x):
+        C = x.shape[-1]
+        return (x.is_cuda and self.elementwise_affine and len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 3072
+                and x.dtype in (torch.float32, torch.bfloat16))
+
+    def _out_dtype(self, x):
+        if torch.is_autocast_enabled():
+            return torch.get_autocast_dtype('cuda') if self.autocast_out else torch.float32
+        return x.dtype
+
+    def forward_with_skip(self, x):
+        """-> (self(x), x') where x' is x for the skip connection of a pre-norm block: in training on MI355X the two gradients of x meet
+        inside the LayerNorm backward kernel (kernels.layer_norm_res); otherwise x' is x."""
+        if self._hip_ok(x) and torch.is_grad_enabled() and x.requires_grad:
+            from .. import kernels
+            if 'ln_res' not in kernels.DISABLED:
+                return kernels.layer_norm_res(x, self.weight, self.bias, self.eps, self._out_dtype(x))
+        return self(x), x
+
     def forward(self, x):
         C = x.shape[-1]
-        if (x.is_cuda and self.elementwise_affine and len(self.normalized_shape) == 1 and C % 4 == 0 and C <= 3072
-                and x.dtype in (torch.float32, torch.bfloat16)):
+        if self._hip_ok(x):
             from .. import kernels
-            out_dtype = x.dtype
-            if torch.is_autocast_enabled():
-                out_dtype = torch.get_autocast_dtype('cuda') if self.autocast_out else torch.float32
-            return kernels.layer_norm(x, self.weight, self.bias, self.eps, out_dtype)
+            return kernels.layer_norm(x, self.weight, self.bias, self.eps, self._out_dtype(x))
         if x.is_cuda:
             from .. import kernels
             kernels.note_fallback('LayerNorm', f'C={C} dtype={x.dtype}')
@@ -386,7 +401,7 @@ class ConvModule(nn.Module):
             if kernels.conv3x3_ok(self.conv, x):              # hand-written MFMA implicit GEMM (forward + data gradient)
                 x = kernels.conv3x3(self.conv, x)
             else:
-                x = self.conv(x)
+                x = kernels.conv_lib(self.conv, x)            # library convolution, weight from the bf16 shadow arena
         else:
             x = self.conv(x)
         if x.is_cuda and self.with_norm and x.dtype in (torch.float32, torch.bfloat16):
@@ -413,7 +428,7 @@ def conv_bias_act(conv, x, slope=1.0):
         return kernels.conv3x3(conv, x, conv.bias, act=slope != 1.0, slope=slope)
     if slope == 1.0 and kernels.conv3x3_c1_ok(conv, x):        # one output channel: streaming kernel, one backward pass for dx / dw / db
         return kernels.conv3x3_c1(conv, x)
-    y = conv._conv_forward(x, conv.weight, None)
+    y = kernels.conv_lib(conv, x)
     if not (y.is_contiguous() or kernels._cl_ok(y)):           # dense NCHW or (vector-sized) channels-last both run in place
         y = y.contiguous()
     return kernels.bias_act_(y, conv.bias, slope)
@@ -449,10 +464,45 @@ class DropPath(nn.Module):
                 kernels.note_fallback('DropPath.residual', f'{identity.dtype}+{branch.dtype} {tuple(identity.shape)} vs {tuple(branch.shape)}')
             return identity + self(branch)
         from .. import kernels
-        keep = 1 - self.drop_prob
-        u = torch.rand((branch.shape[0],) + (1,) * (branch.ndim - 1), dtype=branch.dtype, device=branch.device)
-        scale = ((keep + u).floor().float() / keep).flatten()
-        return kernels.residual_drop_path(identity, branch, scale)
+        return kernels.residual_drop_path(identity, branch, _DROP_PATH_BANK.scale(self, branch.shape[0], branch.dtype, branch.device))
+
+
+class _DropPathBank:
+    """Per-sample keep / (1 - p) scales of ALL DropPath layers of a step from ONE uniform draw: the 22 - 46 stochastic-depth layers of a
+    Swin encoder each cost five tiny launches (rand, add, floor, divide, cast) per step; here layers register on first use and the bank
+    refills every row at once — ``floor(keep + U(L, B)) / keep`` — whenever a layer asks for a row it has already consumed (or the
+    generator was re-seeded since: a run after ``torch.manual_seed`` does not see rows drawn before it).  Same law as
+    ``drop_path`` (one uniform per sample and layer; drawn in fp32, so the keep probability is exact to 2^-24)."""
+
+    def __init__(self):
+        self.layers, self.rows, self.used, self.key, self.keep = [], None, [], None, None
+        self.seed, self.offset = None, 0
+
+    def scale(self, layer, batch, dtype, device):
+        idx = getattr(layer, '_bank_index', None)
+        key = (batch, device)
+        if idx is None or idx >= len(self.layers) or self.layers[idx] is not layer:
+            if len(self.layers) >= 512:                       # models come and go (tests): start over, live layers re-register
+                self.layers = []
+            idx = layer._bank_index = len(self.layers)
+            self.layers.append(layer)
+            self.rows = self.keep = None
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()] if device.type == 'cuda' else None
+        reseeded = gen is not None and (gen.initial_seed(), gen.get_offset() >= self.offset) != (self.seed, True)     # torch.manual_seed since the draw
+        if self.rows is None or self.key != key or self.used[idx] or reseeded:
+            if self.keep is None or self.keep.device != device:
+                self.keep = torch.tensor([1.0 - l.drop_prob for l in self.layers], dtype=torch.float32).view(-1, 1).to(device)
+            u = torch.rand((len(self.layers), batch), dtype=torch.float32, device=device)
+            self.rows = (self.keep + u).floor() / self.keep
+            self.used = [False] * len(self.layers)
+            self.key = key
+            if gen is not None:
+                self.seed, self.offset = gen.initial_seed(), gen.get_offset()
+        self.used[idx] = True
+        return self.rows[idx]
+
+
+_DROP_PATH_BANK = _DropPathBank()
 
 
 _RESIDUAL_DTYPES = {(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)}

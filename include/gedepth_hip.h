@@ -182,6 +182,10 @@ int ge_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
                      float* mean, float* rstd, long rows, int C, float eps, void* stream);
 int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                      const float* rstd, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
+/* The same with the skip-connection gradient folded in: dx = LN'(dy) + dres (dres: x's dtype, NULL = plain backward).  In a pre-norm
+ * block (depthformer_swin.py:396-472: x + attn(LN x)) x feeds the LayerNorm AND the residual; this removes autograd's separate add. */
+int ge_layernorm_bwd_res(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                         const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual connection with per-sample stochastic depth: out[b, :] = identity[b, :] + branch[b, :] * scale[b]

@@ -6,7 +6,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 ARGS="--no-cpu-baseline --no-fp32 --no-h2d --no-kernel-timing --steps 30 --warmup 8"
 python bench.py $ARGS > /dev/null 2>&1          # warm caches
 for round in 1 2; do
-for off in ${AB_LIST:-none conv3x3_c1 conv3x3_wgrad conv3x3 upcat upsum bias_gelu msda_raw conv3x3,conv3x3_c1,conv3x3_wgrad,upcat,upsum,bias_gelu,msda_raw}; do
+for off in ${AB_LIST:-none ln_res conv_lib conv3x3_c1 conv3x3_wgrad conv3x3 upcat upsum bias_gelu msda_raw conv3x3,conv3x3_c1,conv3x3_wgrad,upcat,upsum,bias_gelu,msda_raw}; do
   v=$([ "$off" = none ] && echo "" || echo "$off")
   ms=$(GE_DISABLE="$v" python bench.py $ARGS 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.readline())['ms_per_step'])")
   echo "round $round  GE_DISABLE=$off  $ms ms/step"

@@ -919,13 +919,22 @@ def test_residual_drop_path(dev, dtypes, shape):
     close(ig.grad.float(), ic.grad, what='d identity', **tol)
     assert bg.grad.dtype == tb
     close(bg.grad.float(), bc.grad, what='d branch', **(dict(rtol=2 ** -7, atol=2 ** -7) if tb == torch.bfloat16 else tol))
-    m = DropPath(0.3).to(dev).train()
-    torch.manual_seed(5)
-    fused = m.residual(ident.to(dev), br.to(dev))
-    torch.manual_seed(5)
-    unfused = ident.to(dev) + drop_path(br.to(dev), 0.3, True)
-    # the unfused formula rounds branch / keep to the branch dtype first; the fused pass keeps it in fp32
-    close(fused.float(), unfused.float(), what='module', **(dict(rtol=2 ** -7, atol=2 ** -7) if tb == torch.bfloat16 else tol))
+    # the module: scales come from the shared bank (one uniform draw per step for all DropPath layers, bricks._DropPathBank): every
+    # sample is either dropped (identity) or kept (identity + branch / keep), and the keep rate follows 1 - p
+    m, m2 = DropPath(0.3).to(dev).train(), DropPath(0.6).to(dev).train()
+    kept = [0, 0]
+    for it in range(40):
+        for k, (mod, keep) in enumerate(((m, 0.7), (m2, 0.4))):
+            fused = mod.residual(ident.to(dev), br.to(dev)).float().cpu()
+            lo, hi = ident.float(), ident.float() + br.float() / keep
+            for b_ in range(shape[0]):
+                is_lo = torch.allclose(fused[b_], lo[b_].to(ti).float(), rtol=2 ** -7, atol=2 ** -7)
+                is_hi = torch.allclose(fused[b_], hi[b_], rtol=2 ** -6, atol=2 ** -6)
+                assert is_lo or is_hi, 'a sample is neither dropped nor kept'
+                kept[k] += int(is_hi and not is_lo)
+    n = 40 * shape[0]
+    assert abs(kept[0] / n - 0.7) < 0.15 and abs(kept[1] / n - 0.4) < 0.15, kept
+    assert drop_path(br, 0.0, True) is br
 
 
 @pytest.mark.gpu
@@ -1558,3 +1567,108 @@ def test_conv3x3_one_output_channel_vs_conv2d(dev, geom, out_fp32):
     assert conv.weight.grad.shape == (1, Ci, 3, 3)
     close_scaled(conv.weight.grad.float(), w64.grad, rel=1e-4, what='conv3x3_c1 d_w')
     close_scaled(conv.bias.grad.float(), b64.grad, rel=1e-4, what='conv3x3_c1 d_bias')
+
+
+def test_residual_dropout_and_add_rows(dev):
+    """kernels.residual_dropout (identity + dropout(tokens): forward mask recomputed in backward from the seed) and kernels.add_rows
+    (tokens + fp32 rows broadcast over the batch, gradient to the rows = batch sum) — the self-attention glue of the HAHI neck."""
+    from gedepth_amd import kernels
+    g = gen(53)
+    B, N, C, p = 3, 517, 64, 0.25
+    tok = torch.randn(B, N, C, generator=g).bfloat16().to(dev).requires_grad_(True)
+    idt = torch.randn(B, N, C, generator=g).bfloat16().to(dev).requires_grad_(True)
+    # the mask is a function of (seed, element index): read it off a call with a zero identity
+    with torch.no_grad():
+        plain = kernels.residual_dropout(torch.zeros_like(idt), tok, p, seed=1234).float()
+    kept = (tok.detach().float() / (1 - p)).bfloat16().float()
+    dropped = (plain == 0) & (kept != 0)
+    assert 0.2 < dropped.float().mean().item() < 0.3
+    assert torch.equal(torch.where(dropped, torch.zeros_like(kept), kept), plain)
+    out = kernels.residual_dropout(idt, tok, p, seed=1234)
+    assert torch.equal(out, (plain + idt.detach().float()).bfloat16())                         # dropout(tokens) is rounded, then added: one more rounding
+    diff = out.float() - idt.float()
+    go = torch.randn(B, N, C, generator=g).bfloat16().to(dev)
+    out.backward(go)
+    close_scaled(idt.grad.float(), go.float(), rel=1e-6, what='d_identity')
+    want = torch.where(dropped, torch.zeros_like(diff), go.float() / (1 - p))
+    close_scaled(tok.grad.float(), want, rel=1e-2, what='d_tokens uses the forward mask')
+    out2 = kernels.residual_dropout(idt, tok, p, seed=1234)
+    assert torch.equal(out2, out)                                              # same seed, same mask
+    # add_rows with a gradient for the rows
+    rows = torch.randn(N, C, generator=g).to(dev).requires_grad_(True)
+    t2 = tok.detach().clone().requires_grad_(True)
+    y = kernels.add_rows(t2, rows)
+    ref = (t2.detach().float() + rows.detach()[None]).bfloat16()
+    assert torch.equal(y, ref)
+    y.backward(go)
+    close_scaled(t2.grad.float(), go.float(), rel=1e-6, what='add_rows d_tokens')
+    close_scaled(rows.grad, go.float().sum(0), rel=1e-5, what='add_rows d_rows')
+
+
+def test_conv_lib_reads_the_bf16_shadow(dev):
+    """kernels.conv_lib: the library convolution fed from the optimizer's bf16 shadow weight gives the gradients of the plain autocast
+    convolution (same library kernels, the weight cast is the only thing removed)."""
+    from gedepth_amd import kernels
+    from gedepth_amd.mmrt.optim import FusedAdamW
+    g = gen(54)
+    conv = torch.nn.Conv2d(24, 40, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    conv2 = torch.nn.Conv2d(16, 8, 3, stride=2, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    opt = FusedAdamW(list(conv.parameters()) + list(conv2.parameters()), lr=1e-3)
+    assert getattr(conv.weight, '_ge_lp', None) is not None
+    for c, x in ((conv, torch.randn(2, 24, 9, 11, generator=g)), (conv2, torch.randn(2, 16, 10, 14, generator=g))):
+        x1 = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y1 = kernels.conv_lib(c, x1)
+            y2 = c(x2)
+        assert y1.dtype == torch.bfloat16 and torch.equal(y1, y2)
+        go = torch.randn_like(y1)
+        y1.backward(go)
+        g1 = c.weight.grad.clone()
+        c.weight.grad = None
+        y2.backward(go)
+        assert g1.dtype == torch.float32
+        close_scaled(g1, c.weight.grad, rel=1e-6, what='conv_lib d_w')
+        close_scaled(x1.grad, x2.grad, rel=1e-6, what='conv_lib d_x')
+
+
+@pytest.mark.parametrize('dtypes', ['f32->bf16', 'bf16->bf16', 'f32->f32'])
+def test_layer_norm_with_skip_gradient(dev, dtypes):
+    """kernels.layer_norm_res: (LN(x), x') — the gradient arriving over the skip output is added inside ge_layernorm_bwd_res; against
+    LayerNorm + residual in float64 (the pre-norm block pattern of the Swin encoder), and against the two-kernel composition."""
+    from gedepth_amd import kernels
+    tx, ty = (torch.float32 if t == 'f32' else torch.bfloat16 for t in dtypes.split('->'))
+    g = gen(55)
+    B, N, C = 3, 211, 96
+    x = torch.randn(B, N, C, generator=g).to(tx)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    go_y, go_s = torch.randn(B, N, C, generator=g).to(ty), torch.randn(B, N, C, generator=g).to(tx)
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = F.layer_norm(x64, (C,), w64, b64, 1e-5)
+    (y64 * go_y.double()).sum().backward(retain_graph=True)
+    (x64 * go_s.double()).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    kernels.PROFILER.enable()
+    y, xs = kernels.layer_norm_res(xg, wg, bg, 1e-5, ty)
+    torch.autograd.backward([y, xs], [go_y.to(dev), go_s.to(dev)])
+    kernels.PROFILER.disable()
+    assert any('+res' in r['name'] for r in kernels.PROFILER.summary())
+    assert torch.equal(xs, xg)
+    tol = 2e-2 if torch.bfloat16 in (tx, ty) else 1e-5
+    close_scaled(y.float(), y64, rel=tol, what='y')
+    close_scaled(xg.grad.float(), x64.grad, rel=tol, what='d_x = LN bwd + skip')
+    close_scaled(wg.grad, w64.grad, rel=tol, what='d_gamma')
+    close_scaled(bg.grad, b64.grad, rel=tol, what='d_beta')
+    # skip output unused -> plain backward; LN output unused -> pass-through
+    x2 = x.to(dev).requires_grad_(True)
+    y2, _ = kernels.layer_norm_res(x2, wg, bg, 1e-5, ty)
+    y2.backward(go_y.to(dev))
+    x3 = x.to(dev).requires_grad_(True)
+    y3 = kernels.layer_norm(x3, wg, bg, 1e-5, ty)
+    y3.backward(go_y.to(dev))
+    assert torch.equal(x2.grad, x3.grad)
+    x4 = x.to(dev).requires_grad_(True)
+    _, s4 = kernels.layer_norm_res(x4, wg, bg, 1e-5, ty)
+    s4.backward(go_s.to(dev))
+    assert torch.equal(x4.grad, go_s.to(dev))
