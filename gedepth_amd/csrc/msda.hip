@@ -558,35 +558,47 @@ __global__ void __launch_bounds__(256) msda_segscan_k(MsdaWs ws, int ntiles, int
   for (int r = 0; r < R; ++r) { const int c = p[(long)r * ntiles]; p[(long)r * ntiles] = run; run += c; }
 }
 
-__global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
-  __shared__ long s_off[1024];
-  __shared__ int s_chk[1024];
-  __shared__ long carry_off;
-  __shared__ int carry_chk;
-  if (threadIdx.x == 0) { carry_off = 0; carry_chk = 0; }
-  __syncthreads();
-  for (int base = 0; base < nbins; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int c = i < nbins ? ws.cnt[i] : 0;
-    const int k = (c + MSDA_CHUNK - 1) / MSDA_CHUNK;
-    s_off[threadIdx.x] = c; s_chk[threadIdx.x] = k;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan
-      long vo = 0; int vk = 0;
-      if ((int)threadIdx.x >= d) { vo = s_off[threadIdx.x - d]; vk = s_chk[threadIdx.x - d]; }
-      __syncthreads();
-      s_off[threadIdx.x] += vo; s_chk[threadIdx.x] += vk;
-      __syncthreads();
-    }
-    if (i < nbins) {
-      ws.offset[i] = carry_off + s_off[threadIdx.x] - c;
-      ws.chunk_first[i] = carry_chk + s_chk[threadIdx.x] - k;
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) { carry_off += s_off[1023]; carry_chk += s_chk[1023]; }
-    __syncthreads();
+// exclusive scans of the bin counts (-> first record slot) and of the bins' chunk counts (-> first chunk index).  One workgroup of 16
+// waves; wave w owns the contiguous segment [w * seg, (w + 1) * seg) and walks it 64 bins at a time (coalesced), scanning each batch with
+// lane shuffles: pass 1 totals per wave, 16-entry scan, pass 2 writes.  (The first version ran a 1024-wide Hillis-Steele scan with 20
+// barriers for every 1024 bins: 170 us for 70 k bins; this one is a few microseconds.)
+__device__ __forceinline__ void msda_wave_scan(long& vo, int& vk, int lane) {      // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long o = __shfl_up(vo, d, 64);
+    const int k = __shfl_up(vk, d, 64);
+    if (lane >= d) { vo += o; vk += k; }
   }
-  if (threadIdx.x == 0) { ws.chunk_first[nbins] = carry_chk; ws.ctrl[0] = carry_chk; }
+}
+__global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
+  __shared__ long w_off[16];
+  __shared__ int w_chk[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int seg = ((nbins + 15) / 16 + 63) / 64 * 64;
+  const int lo = wv * seg, hi = min(nbins, lo + seg);
+  long to = 0; int tk = 0;
+  for (int i = lo + lane; i < hi; i += 64) { const int c = ws.cnt[i]; to += c; tk += (c + MSDA_CHUNK - 1) / MSDA_CHUNK; }
+#pragma unroll
+  for (int d = 32; d; d >>= 1) { to += __shfl_xor(to, d, 64); tk += __shfl_xor(tk, d, 64); }
+  if (lane == 0) { w_off[wv] = to; w_chk[wv] = tk; }
+  __syncthreads();
+  long run_o = 0; int run_k = 0;
+  for (int w = 0; w < wv; ++w) { run_o += w_off[w]; run_k += w_chk[w]; }
+  for (int base = lo; base < hi; base += 64) {
+    const int i = base + lane;
+    const int c = i < hi ? ws.cnt[i] : 0;
+    const int k = (c + MSDA_CHUNK - 1) / MSDA_CHUNK;
+    long vo = c; int vk = k;
+    msda_wave_scan(vo, vk, lane);
+    if (i < hi) { ws.offset[i] = run_o + vo - c; ws.chunk_first[i] = run_k + vk - k; }
+    run_o += __shfl(vo, 63, 64);
+    run_k += __shfl(vk, 63, 64);
+  }
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += w_chk[w];
+    ws.chunk_first[nbins] = total; ws.ctrl[0] = total;
+  }
   if (threadIdx.x >= 1 && threadIdx.x < 2 + MSDA_XCDS) ws.ctrl[threadIdx.x] = 0;      // per-XCD work cursors
 }
 

@@ -24,6 +24,9 @@ def ours(x_cl, w_ohwi, bias, act, slope):
     return y
 shapes = [(8, 176, 560, 576, 64), (8, 176, 560, 160, 64), (8, 176, 560, 64, 64), (8, 88, 280, 288, 96), (8, 88, 280, 608, 96), (8, 88, 280, 96, 96),
           (8, 44, 140, 576, 192), (8, 44, 140, 704, 192), (8, 22, 70, 1152, 384), (8, 22, 70, 896, 384), (8, 11, 35, 1280, 768), (2, 13, 37, 64, 96)]
+import os
+if os.environ.get('CONV_ONLY'):
+    shapes = [(8, 176, 560, 576, 64), (8, 88, 280, 288, 96)]
 for N, H, W, Ci, Co in shapes:
     torch.manual_seed(0)
     x = torch.randn(N, Ci, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
