@@ -692,7 +692,7 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, bias, act, slope):
         x = _cl(x.to(torch.bfloat16))
         from .mmrt.optim import lowp
-        wb = lowp(weight.detach(), torch.bfloat16)                             # the optimizer's bf16 shadow when current: no cast kernel
+        wb = lowp(weight, torch.bfloat16).detach()                             # the optimizer's bf16 shadow when current: no cast kernel
         if not wb.is_contiguous(memory_format=_CL):
             wb = wb.contiguous(memory_format=_CL)
         w_ohwi = wb.permute(0, 2, 3, 1)                                      # a view: the channels-last storage IS (O, H, W, I)
@@ -772,7 +772,7 @@ class _ConvLib(torch.autograd.Function):
         from .mmrt.optim import lowp
         dt = torch.get_autocast_dtype('cuda')
         with torch.autocast('cuda', enabled=False):
-            xc, wc = x.to(dt), lowp(weight.detach(), dt)
+            xc, wc = x.to(dt), lowp(weight, dt).detach()
             y = torch.nn.functional.conv2d(xc, wc, None, stride, padding, dilation, groups)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (stride, padding, dilation, groups, x.dtype, weight.dtype)
