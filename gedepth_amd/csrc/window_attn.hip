@@ -10,6 +10,7 @@
 // This variant does the contractions as fp32 FMA chains (bit-equivalent to an fp32-input MFMA, which runs
 // at the same rate on gfx950 — MI355X_MICROARCH.md), and is the parity path; window_attn_mfma.hip holds the
 // bf16 MFMA tile variant.
+#include <stdlib.h>
 #include "common.h"
 #include "window_attn.h"
 
@@ -266,7 +267,13 @@ static int win_geom(int B, int H, int W, int nH, int shift, WinGeom& g) {
 }
 static int bwd_wg_per_head(const WinGeom& g) {
   long n_bw = (long)g.B * g.nWh * g.nWw;
-  long want = (256L * 6 + g.nH - 1) / g.nH;      // ~6 single-wave workgroups per CU
+  static const int per_cu = [] { const char* e = getenv("GE_WINATTN_WPC"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 32 ? v : 8; }();
+  long want = (256L * per_cu + g.nH - 1) / g.nH;  // persistent workgroups per CU: 4 are resident (two waves per SIMD, two waves each); 8 measured best (4: +4 %, 6: +3 %)
+  // every persistent workgroup ends with the bias-table scatter (64 LDS atomic instructions per wave) and a workspace row for the second
+  // reduction stage: keep at least `min_win` windows per workgroup so that this epilogue is amortised (coarse stages have few windows)
+  static const int min_win = [] { const char* e = getenv("GE_WINATTN_MINWIN"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 3; }();
+  const long cap = (n_bw + min_win - 1) / min_win;
+  if (want > cap) want = cap;
   if (want > n_bw) want = n_bw;
   if (want < 1) want = 1;
   return (int)want;

@@ -18,6 +18,7 @@
 //
 // HBM traffic is the algorithmic minimum: q,k,v (+dO) read once, out (dqkv) written once; the op is HBM-bound
 // (24.5 FLOP/B at bf16, ridge 312 FLOP/B) and MFMA only has to keep the arithmetic off the critical path.
+#include <stdlib.h>
 #include "common.h"
 #include "window_attn.h"
 
@@ -520,6 +521,226 @@ __global__ void __launch_bounds__(64) window_attn_bwd_mfma_k(const bf16_t* __res
   wsp[NBIAS + lane] = sm.dpad[lane];
 }
 
+// ------------------------------------------------------------------------------------------- backward, two waves per (window, head)
+// The single-wave kernel above holds P, dS, dB, dQ, dK, dV for both 32-query tiles at once: 256 VGPR + 93 AGPR = one wave per SIMD, four
+// (window, head) items in flight per CU, each with 25 - 30 us of exposed latency (staging by one wave, eight barriers, four LDS transposes).
+// Here wave w of a 128-thread workgroup owns QUERY TILE w: scores, soft-max, dP, dS, the bias-table gradient and dQ of its 32 queries are
+// wave-local (half the registers: two waves per SIMD), the four operand tiles are staged by both waves, and only the key-side sums
+// dK / dV = sum over ALL queries meet: each wave sends its partial for the other wave's key tile through LDS (8 KB each way, in the space
+// of the dead operand tiles) and finishes its own key tile.
+__device__ __forceinline__ void st_tiles_q(const bf16_t* A_rows, const bf16_t* B_rows, int qt, int c, int hi, f32x16 acc[2]) {
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[kt][i] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8 a0 = row8(A_rows, c, ks * 16 + hi * 8), a1 = row8(A_rows, 32 + c, ks * 16 + hi * 8);
+    const bf16x8 b = row8(B_rows, qt * 32 + c, ks * 16 + hi * 8);
+    acc[0] = mfma_bf16(a0, b, acc[0]);
+    acc[1] = mfma_bf16(a1, b, acc[1]);
+  }
+}
+// softmax_cols for one query tile: the lane owns query column qt * 32 + c
+__device__ __forceinline__ void softmax_q(f32x16 acc[2], const float* bias, const uint32_t* meta, int qt, int c, int hi, float scale,
+                                          bool use_mask) {
+  const int q = qt * 32 + c;
+  const uint32_t mq = meta[q < WT ? q : 0];
+  const int qb = (int)(mq & 0xffffu) + 6 * 13 + 6;
+  const int rq = (int)(mq >> 16);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + crow(r, hi);
+      float sc = -INFINITY;
+      if (key < WT) {
+        const uint32_t mk = meta[key];
+        sc = acc[kt][r] * scale + bias[qb - (int)(mk & 0xffffu)];
+        if (use_mask && (int)(mk >> 16) != rq) sc += -100.0f;
+      }
+      acc[kt][r] = sc;
+      mx = fmaxf(mx, sc);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(acc[kt][r] - mx);
+      acc[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kt][r] *= inv;
+}
+
+struct WinSmemMfmaBwd2 {
+  bf16_t k[64 * RLD];       // k | q | v | go are contiguous: 20 KB, re-used for the transposes and the dK / dV exchange
+  bf16_t q[64 * RLD];
+  bf16_t v[64 * RLD];
+  bf16_t go[64 * RLD];
+  float bias[NBIAS + 7];
+  float dbias[NBIAS + 7];
+  float dpad[2][2 * HD];    // per wave
+  WinMeta m;
+};
+__global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                  const float* __restrict__ bias_table, const bf16_t* __restrict__ gout,
+                                                                  bf16_t* __restrict__ dqkv, float* __restrict__ workspace,
+                                                                  WinGeom g, float scale, int wg_per_head) {
+  __shared__ __attribute__((aligned(16))) WinSmemMfmaBwd2 sm;
+  const int tid = threadIdx.x, lane = tid & 63, qt = tid >> 6, c = lane & 31, hi = lane >> 5;
+  const int head = blockIdx.x % g.nH;
+  const int slot = blockIdx.x / g.nH;
+  const int nW = g.nWh * g.nWw;
+  const int n_bw = g.B * nW;
+  const long L = (long)g.H * g.W;
+  for (int i = tid; i < NBIAS; i += 128) { sm.bias[i] = bias_table[i * g.nH + head]; sm.dbias[i] = 0.f; }
+  if (tid < 2 * HD) { sm.dpad[0][tid] = 0.f; sm.dpad[1][tid] = 0.f; }
+  __syncthreads();
+  f32x16 dB[2];                                              // bias-table gradient of this wave's query tile, summed over the windows
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dB[kt][i] = 0.f;
+
+  for (int bw = slot; bw < n_bw; bw += wg_per_head) {
+    const int b = bw / nW, win = bw - b * nW;
+    const int wy = win / g.nWw, wx = win - wy * g.nWw;
+    if (qt == 0) fill_meta(g, wy, wx, lane, sm.m);
+    __syncthreads();
+    const bf16_t* base = qkv + (long)b * L * 3 * g.C;
+    if (qt == 0) {
+      stage_rm(base, 3 * g.C, head * HD, sm.m.tok, qkv_bias, sm.q, lane);
+      stage_rm(base, 3 * g.C, g.C + head * HD, sm.m.tok, qkv_bias, sm.k, lane);
+    } else {
+      stage_rm(base, 3 * g.C, 2 * g.C + head * HD, sm.m.tok, qkv_bias, sm.v, lane);
+      stage_rm(gout + (long)b * L * g.C, g.C, head * HD, sm.m.tok, nullptr, sm.go, lane);
+    }
+    __syncthreads();
+
+    f32x16 P[2], dS[2];
+    st_tiles_q(sm.k, sm.q, qt, c, hi, P);
+    const bool use_mask = g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
+    softmax_q(P, sm.bias, sm.m.meta, qt, c, hi, scale, use_mask);
+    st_tiles_q(sm.v, sm.go, qt, c, hi, dS);                  // dP^T = V dO^T for this wave's queries
+    {
+      float delta = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) delta += P[kt][r] * dS[kt][r];
+      delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ds = P[kt][r] * (dS[kt][r] - delta);     // exactly 0 for rows / columns >= 49 (P == 0 there)
+          dS[kt][r] = ds;
+          dB[kt][r] += ds;
+        }
+    }
+    // dQ^T[d][query] = scale * sum_key K^T[d][key] dS^T[key][query]
+    {
+      f32x16 dq;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) dq = mfma_bf16(col8(sm.k, kt * 32 + 16 * s + 4 * hi, c), pack8(dS[kt], 8 * s), dq);
+      const int q = qt * 32 + c;
+      if (q < WT) {
+        const int dst = sm.m.tok[q];
+        if (dst >= 0) store_cols(dq, scale, dqkv + ((long)b * L + dst) * 3 * g.C + head * HD, hi);
+      }
+    }
+    __syncthreads();                                         // both waves are done with V (dP) and K (dQ): they become the transpose buffers
+
+    // partial dV^T[d][key] = sum_{q in tile} dO^T[d][q] P[q][key];  partial dK^T[d][key] = sum_{q in tile} Q^T[d][q] dS[q][key]
+    f32x16 dv[2], dk[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { dv[kt][i] = 0.f; dk[kt][i] = 0.f; }
+    bf16_t* tb = qt == 0 ? sm.v : sm.k;                      // [64 keys][RLD], columns 0..31 = the queries of this wave's tile
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {                   // pass 0: P -> dV ; pass 1: dS -> dK
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[(kt * 32 + crow(r, hi)) * RLD + c] = f2bf_hw(pass == 0 ? P[kt][r] : dS[kt][r]);
+      __syncthreads();
+      const bf16_t* lhs = pass == 0 ? sm.go : sm.q;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 a = col8_lin(lhs, qt * 32 + ks * 16 + hi * 8, c);    // X^T[d = c][8 consecutive queries]
+        const bf16x8 b0 = row8(tb, c, ks * 16 + hi * 8), b1 = row8(tb, 32 + c, ks * 16 + hi * 8);
+        if (pass == 0) { dv[0] = mfma_bf16(a, b0, dv[0]); dv[1] = mfma_bf16(a, b1, dv[1]); }
+        else { dk[0] = mfma_bf16(a, b0, dk[0]); dk[1] = mfma_bf16(a, b1, dk[1]); }
+      }
+      __syncthreads();
+    }
+    // every operand tile is dead now: the two waves swap their partials for each other's key tile through the same LDS
+    {
+      float* xb = (float*)sm.k;                              // k | q | v | go = 20 KB; 8 KB per wave are used
+      const int other = 1 - qt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        xb[qt * 2048 + r * 64 + lane] = other == 0 ? dk[0][r] : dk[1][r];
+        xb[qt * 2048 + 1024 + r * 64 + lane] = other == 0 ? dv[0][r] : dv[1][r];
+      }
+      __syncthreads();
+      f32x16 dkm, dvm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dkm[r] = (qt == 0 ? dk[0][r] : dk[1][r]) + xb[other * 2048 + r * 64 + lane];
+        dvm[r] = (qt == 0 ? dv[0][r] : dv[1][r]) + xb[other * 2048 + 1024 + r * 64 + lane];
+      }
+      const int key = qt * 32 + c;                           // this wave finishes key tile qt
+      if (key < WT) {
+        const int dst = sm.m.tok[key];
+        if (dst >= 0) {
+          bf16_t* rp = dqkv + ((long)b * L + dst) * 3 * g.C + head * HD;
+          store_cols(dkm, scale, rp + g.C, hi);
+          store_cols(dvm, 1.f, rp + 2 * g.C, hi);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            atomicAdd(&sm.dpad[qt][crow(r, hi)], dkm[r] * scale);         // per-wave accumulators: the sum order stays fixed
+            atomicAdd(&sm.dpad[qt][HD + crow(r, hi)], dvm[r]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int w = 0; w < 2; ++w) {                                // wave after wave: a fixed summation order, bit-reproducible gradients
+    if (qt == w) {
+      const int q = qt * 32 + c;
+      const int qb = (q / WS) * 13 + (q % WS) + 6 * 13 + 6;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + crow(r, hi);
+          if (q < WT && key < WT) atomicAdd(&sm.dbias[qb - ((key / WS) * 13 + key % WS)], dB[kt][r]);
+        }
+    }
+    __syncthreads();
+  }
+  float* wsp = workspace + (long)blockIdx.x * WS_PER_WG_MFMA;
+  for (int i = tid; i < NBIAS; i += 128) wsp[i] = sm.dbias[i];
+  if (tid < 2 * HD) wsp[NBIAS + tid] = sm.dpad[0][tid] + sm.dpad[1][tid];
+}
+
 extern const int ge_window_attn_mfma_available = 3;   // bit0: forward, bit1: backward
 
 int ge_window_attn_fwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, void* out, const WinGeom& g,
@@ -534,9 +755,15 @@ int ge_window_attn_fwd_mfma(const void* qkv, const float* qkv_bias, const float*
 }
 int ge_window_attn_bwd_mfma(const void* qkv, const float* qkv_bias, const float* bias_table, const void* d_out, void* d_qkv,
                             float* workspace, const WinGeom& g, float scale, int wg_per_head, hipStream_t s) {
-  window_attn_bwd_mfma_k<<<(unsigned)(wg_per_head * g.nH), 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table,
-                                                                       (const bf16_t*)d_out, (bf16_t*)d_qkv, workspace, g,
-                                                                       scale, wg_per_head);
+  static const int two_wave = [] { const char* e = getenv("GE_WINATTN_BWD"); return !(e && e[0] == '1') ? 1 : 0; }();     // GE_WINATTN_BWD=1: single-wave kernel (A/B)
+  if (two_wave)
+    window_attn_bwd_mfma2_k<<<(unsigned)(wg_per_head * g.nH), 128, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table,
+                                                                           (const bf16_t*)d_out, (bf16_t*)d_qkv, workspace, g,
+                                                                           scale, wg_per_head);
+  else
+    window_attn_bwd_mfma_k<<<(unsigned)(wg_per_head * g.nH), 64, 0, s>>>((const bf16_t*)qkv, qkv_bias, bias_table,
+                                                                         (const bf16_t*)d_out, (bf16_t*)d_qkv, workspace, g,
+                                                                         scale, wg_per_head);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
