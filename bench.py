@@ -346,16 +346,21 @@ def main():
 
     # ---- reference-precision (fp32, exact-fp32 attention off: library fp32 GEMM/conv + the same HIP kernels) line at N=1
     if world == 1 and args.dtype != 'fp32' and not args.no_fp32:
-        # the committed MIOpen find-db holds the bf16 problems only: with find mode on, every fp32 convolution would be
-        # timed from scratch (minutes); the fp32 line uses MIOpen's immediate-mode heuristics instead
-        torch.backends.cudnn.benchmark = False
+        # the committed MIOpen find-db holds the fp32 problems of the DEFAULT workload (tools/tune_tables.py --dtype fp32): find mode
+        # resolves them from the db; for any other workload every fp32 convolution would be timed from scratch (minutes), so those
+        # use MIOpen's immediate-mode heuristics (GE_FP32_FIND=0 forces that for the default workload too)
+        default_workload = (args.config == 'depthformer_swint_v.py' and args.height == 352 and args.width == 1120 and args.batch in (None, 8)
+                            and args.layout == 'nhwc')
+        fp32_find = bool(torch.backends.cudnn.benchmark) and default_workload and os.environ.get('GE_FP32_FIND', '1') != '0'
+        torch.backends.cudnn.benchmark = fp32_find
         note('fp32 leg')
         step32, _, opt32 = build_job(args, cfg, dev, rank, 'fp32')
         e32, o32 = timed_steps(step32, 2, args.fp32_steps, dev, world)
         if rank == 0:
             res['fp32'] = {'value': round(per_gpu * args.fp32_steps / e32, 3), 'unit': 'img/s', 'ms_per_step': round(1e3 * e32 / args.fp32_steps, 3),
                            'steps': args.fp32_steps, 'warmup': 2, 'dtype': 'fp32', 'last_loss': round(float(o32['log_vars']['loss']), 5),
-                           'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision; exact-fp32 window attention, MIOpen immediate mode)'}
+                           'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision; exact-fp32 window attention, MIOpen '
+                                   + ('find mode from the committed find-db)' if fp32_find else 'immediate mode)')}
         del step32, opt32, o32
         torch.cuda.empty_cache()
     if rank == 0:

@@ -6,6 +6,7 @@
 
     python tools/tune_tables.py --config depthformer_swint_v.py                       # the bench workload (8 x 352 x 1120)
     python tools/tune_tables.py --config depthformer_a.py --batch 2                   # Swin-L + GEDepth-Adaptive
+    python tools/tune_tables.py --dtype fp32                                          # the fp32 problems of the bench workload
 
 Existing entries are kept (both tables are seeded from the committed files and appended to); takes ~5-8 minutes per
 workload, almost all of it MIOpen's solver timing.  Nothing here runs during training or benchmarking: those only look
@@ -29,6 +30,7 @@ def main():
     ap.add_argument('--height', type=int, default=352)
     ap.add_argument('--width', type=int, default=1120)
     ap.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'], help='fp32: the convolutions / GEMMs of the reference-precision step (the drop-in default)')
     ap.add_argument('--out-dir', default=None, help='also copy the updated tables here (e.g. gpurun_out/tuning on the GPU box)')
     a = ap.parse_args()
     work = tempfile.mkdtemp(prefix='gedepth_tune_')
@@ -42,7 +44,7 @@ def main():
                PYTORCH_TUNABLEOP_MAX_WARMUP_DURATION_MS='5')
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--config', a.config, '--steps', '3', '--warmup', '3', '--no-cpu-baseline',
            '--no-kernel-timing', '--cudnn-benchmark', '1', '--gemm-tuning', 'tune', '--height', str(a.height), '--width', str(a.width), '--layout', a.layout,
-           '--no-fp32']
+           '--no-fp32', '--dtype', a.dtype, '--no-h2d']
     if a.batch:
         cmd += ['--batch', str(a.batch)]
     subprocess.run(cmd, env=env, check=True)
