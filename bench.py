@@ -355,10 +355,10 @@ def main():
         torch.backends.cudnn.benchmark = fp32_find
         note('fp32 leg')
         step32, _, opt32 = build_job(args, cfg, dev, rank, 'fp32')
-        e32, o32 = timed_steps(step32, 2, args.fp32_steps, dev, world)
+        e32, o32 = timed_steps(step32, 4, args.fp32_steps, dev, world)
         if rank == 0:
             res['fp32'] = {'value': round(per_gpu * args.fp32_steps / e32, 3), 'unit': 'img/s', 'ms_per_step': round(1e3 * e32 / args.fp32_steps, 3),
-                           'steps': args.fp32_steps, 'warmup': 2, 'dtype': 'fp32', 'last_loss': round(float(o32['log_vars']['loss']), 5),
+                           'steps': args.fp32_steps, 'warmup': 4, 'dtype': 'fp32', 'last_loss': round(float(o32['log_vars']['loss']), 5),
                            'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision; exact-fp32 window attention, MIOpen '
                                    + ('find mode from the committed find-db)' if fp32_find else 'immediate mode)')}
         del step32, opt32, o32
