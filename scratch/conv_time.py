@@ -27,6 +27,10 @@ shapes = [(8, 176, 560, 576, 64), (8, 176, 560, 160, 64), (8, 176, 560, 64, 64),
 import os
 if os.environ.get('CONV_ONLY'):
     shapes = [(8, 176, 560, 576, 64), (8, 88, 280, 288, 96)]
+if os.environ.get('CONV_SWINL'):                                   # config #3: Swin-L + GEDepth-Adaptive, 2 images per GPU
+    shapes = [(2, 176, 560, 576, 64), (2, 88, 280, 704, 192), (2, 88, 280, 576, 192), (2, 44, 140, 1152, 384), (2, 22, 70, 2304, 768), (2, 176, 560, 64, 64),
+              (2, 44, 140, 896, 384), (2, 176, 560, 256, 64), (2, 22, 70, 1280, 768), (2, 22, 70, 768, 768), (2, 11, 35, 2048, 1536), (2, 88, 280, 192, 192),
+              (2, 44, 140, 384, 384), (2, 88, 280, 192, 64), (1, 608, 968, 576, 64), (1, 304, 484, 704, 192), (1, 152, 242, 1152, 384)]
 for N, H, W, Ci, Co in shapes:
     torch.manual_seed(0)
     x = torch.randn(N, Ci, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
