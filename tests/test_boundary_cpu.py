@@ -218,3 +218,39 @@ def test_tuning_tables_are_lookup_only(monkeypatch, tmp_path):
     assert tuning.use_tuned_gemms('off') is False
     with pytest.raises(ValueError):
         tuning.use_tuned_gemms('sometimes')
+
+
+def test_drop_path_bank_serves_every_layer_once_per_draw():
+    """mmrt.bricks._DropPathBank (host logic of the fused DropPath residual): layers register on first use, every refill draws one
+    uniform per (layer, sample), a layer asking twice triggers a refill, scales are 0 or 1 / keep and the keep rate follows 1 - p."""
+    import torch
+    from gedepth_amd.mmrt.bricks import DropPath, _DropPathBank
+    bank = _DropPathBank()
+    layers = [DropPath(p) for p in (0.1, 0.5, 0.9)]
+    dev = torch.device('cpu')
+    torch.manual_seed(3)
+    for l in layers:                                                     # registration pass (every new layer forces a refill)
+        bank.scale(l, 6, torch.float32, dev)
+    assert len(bank.layers) == 3
+    refills, last = 0, None
+    seen = {i: [] for i in range(3)}
+    for _ in range(5):                                                   # five "steps": layers run in order, each asks once per step
+        for i, l in enumerate(layers):
+            r = bank.scale(l, 6, torch.float32, dev)
+            keep = 1 - l.drop_prob
+            assert r.shape == (6,) and bool(((r == 0) | ((r - 1 / keep).abs() < 1e-6)).all()) and bank.used[i]
+            if bank.rows is not last:
+                refills, last = refills + 1, bank.rows
+            seen[i].append(r.clone())
+    assert refills <= 6                                                  # one draw per step serves all layers (not one per layer)
+    assert any(not torch.equal(a, b) for a, b in zip(seen[0][:-1], seen[0][1:]))     # a layer never sees the same draw twice in a row
+    kept = torch.zeros(3)
+    n = 400
+    for _ in range(n):
+        for i, l in enumerate(layers):
+            kept[i] += (bank.scale(l, 6, torch.float32, dev) > 0).float().mean()
+    for i, l in enumerate(layers):
+        assert abs(kept[i].item() / n - (1 - l.drop_prob)) < 0.06, (i, kept[i].item() / n)
+    late = DropPath(0.2)                                                 # a layer that shows up later joins the bank
+    assert bank.scale(late, 6, torch.float32, dev).shape == (6,) and len(bank.layers) == 4
+    assert bank.scale(layers[1], 4, torch.float32, dev).shape == (4,)    # another batch size: refill
