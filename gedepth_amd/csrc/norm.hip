@@ -88,8 +88,14 @@ __global__ void __launch_bounds__(256) layernorm_bwd_k(const TY* __restrict__ dy
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, TX* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int C,
-                                                       int use_lds, const TX* __restrict__ dres) {
+                                                       int use_lds, const TX* __restrict__ dres, int copies) {
   constexpr int RPB = 256 / GS;
+  // copies > 1: dgamma points at [copies][2][C] floats (dbeta = dgamma + C): workgroup w adds into copy w % copies — same-address fp32
+  // atomics serialise in L2 (1024 workgroups on one copy: ~22 us per launch); the CALLER sums the copies.  (Folding them in the last
+  // workgroup to finish was tried: the device-scope fence it needs writes the XCD's dirty L2 lines back — the kernel's own dx stream —
+  // and doubled the kernel time: 141 vs 68 us at 197120 x 96.)
+  const long copy_off = copies > 1 ? (long)(blockIdx.x % copies) * 2 * C : 0;
+  dgamma += copy_off; dbeta += copy_off;
   extern __shared__ float red[];                       // [RPB][2][C] when use_lds (column sums across the row groups)
   const int sub = threadIdx.x % GS, rg = threadIdx.x / GS;
   const float inv_c = 1.f / (float)C;
@@ -213,15 +219,22 @@ static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, v
 }
 template <typename TX, typename TY>
 static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
-                         float* dgamma, float* dbeta, long rows, int C, hipStream_t s, const void* dres = nullptr) {
+                         float* dgamma, float* dbeta, long rows, int C, hipStream_t s, const void* dres = nullptr, int copies = 1) {
   LnPlan pl;
   if (!ln_plan(C, pl)) return GE_ERR_UNSUPPORTED;
   const int rpb = 256 / pl.gs;
-  const unsigned blocks = ge_blocks(rows, rpb * 8, 256 * 4);          // few, long-lived workgroups: fewer column atomics
+  // few, long-lived workgroups keep the column atomics down (1024 workgroups: ~22 us of serialised adds per launch) — but a workgroup walks
+  // its rows rpb at a time with a full memory round trip per step, so small inputs must not be dealt 8 steps to 100 workgroups
+  // (3080 x 768: 35 us for 14 MB): aim at ~768 workgroups, between 1 and 8 steps each
+  long per = (rows + 767) / 768;
+  per = (per + rpb - 1) / rpb * rpb;
+  if (per < rpb) per = rpb;
+  if (per > rpb * 8) per = rpb * 8;
+  const unsigned blocks = ge_blocks(rows, (int)per, 256 * 4);
   size_t smem = (size_t)rpb * 2 * C * sizeof(float);
   const int use_lds = smem <= 60 * 1024;                               // else: per-lane column atomics (only LN(3072), few rows)
   if (!use_lds) smem = 0;
-#define LN_B(GS_, N_) layernorm_bwd_k<TX, TY, GS_, N_><<<blocks, 256, smem, s>>>((const TY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, C, use_lds, (const TX*)dres)
+#define LN_B(GS_, N_) layernorm_bwd_k<TX, TY, GS_, N_><<<blocks, 256, smem, s>>>((const TY*)dy, (const TX*)x, gamma, mean, rstd, (TX*)dx, dgamma, dbeta, rows, C, use_lds, (const TX*)dres, copies)
 #define LN_B16(N_) LN_B(16, N_)
 #define LN_B32(N_) LN_B(32, N_)
 #define LN_B64(N_) LN_B(64, N_)
@@ -271,6 +284,22 @@ extern "C" int ge_layernorm_bwd_res(const void* dy, int y_dtype, const void* x, 
   if (x_dtype == GE_F32 && y_dtype == GE_BF16) return ln_bwd_launch<float, bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
   if (x_dtype == GE_BF16 && y_dtype == GE_BF16) return ln_bwd_launch<bf16_t, bf16_t>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
   if (x_dtype == GE_BF16 && y_dtype == GE_F32) return ln_bwd_launch<bf16_t, float>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, s, dres);
+  return GE_ERR_UNSUPPORTED;
+}
+
+// ge_layernorm_bwd_res with the column sums spread over `copies` accumulators: dgb = [copies][2][C] floats (gamma row, beta row), zero-filled by
+// the caller; d_gamma = sum over copies of dgb[k][0][:], d_beta = sum of dgb[k][1][:] (the caller's one small reduction).
+extern "C" int ge_layernorm_bwd_multi(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                                      const float* rstd, const void* dres, void* dx, float* dgb, int copies, long rows, int C, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgb || rows < 0 || C <= 0 || copies < 1 || copies > 64) return GE_ERR_BAD_ARG;
+  if (rows == 0) return GE_OK;
+  hipStream_t s = ge_stream(stream);
+  float* dg = dgb;
+  float* db = dgb + C;
+  if (x_dtype == GE_F32 && y_dtype == GE_F32) return ln_bwd_launch<float, float>(dy, x, gamma, mean, rstd, dx, dg, db, rows, C, s, dres, copies);
+  if (x_dtype == GE_F32 && y_dtype == GE_BF16) return ln_bwd_launch<float, bf16_t>(dy, x, gamma, mean, rstd, dx, dg, db, rows, C, s, dres, copies);
+  if (x_dtype == GE_BF16 && y_dtype == GE_BF16) return ln_bwd_launch<bf16_t, bf16_t>(dy, x, gamma, mean, rstd, dx, dg, db, rows, C, s, dres, copies);
+  if (x_dtype == GE_BF16 && y_dtype == GE_F32) return ln_bwd_launch<bf16_t, float>(dy, x, gamma, mean, rstd, dx, dg, db, rows, C, s, dres, copies);
   return GE_ERR_UNSUPPORTED;
 }
 

@@ -941,6 +941,9 @@ def upsum(fine, coarse_maps, align_corners=True):
 
 
 # ------------------------------------------------------------------------------ layer norm
+_LN_COPIES = max(1, min(64, int(os.environ.get('GE_LN_COPIES', '8'))))      # accumulators of the d_gamma / d_beta column sums (same-address fp32 atomics serialise in L2)
+
+
 class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
@@ -968,11 +971,12 @@ class _LayerNorm(torch.autograd.Function):
         if dy.dtype not in (_f32, torch.bfloat16):
             dy = dy.to(_f32)
         dx = torch.empty_like(x)
-        dwb = torch.zeros(2, C, device=x.device, dtype=_f32)
+        dwb = torch.zeros(_LN_COPIES, 2, C, device=x.device, dtype=_f32)                       # see ge_layernorm_bwd_multi
         PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}]', 2 * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
-            hip.lib().ge_layernorm_bwd(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
-                                       hip.ptr(rstd), hip.ptr(dx), hip.ptr(dwb[0]), hip.ptr(dwb[1]), rows, C, hip.stream()),
-            'ge_layernorm_bwd'))
+            hip.lib().ge_layernorm_bwd_multi(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
+                                             hip.ptr(rstd), None, hip.ptr(dx), hip.ptr(dwb), _LN_COPIES, rows, C, hip.stream()),
+            'ge_layernorm_bwd_multi'))
+        dwb = dwb.sum(0)
         return dx, dwb[0], dwb[1], None, None
 
 
@@ -1010,12 +1014,13 @@ class _LayerNormRes(torch.autograd.Function):
         if dres is not None:
             dres = _c(dres.to(x.dtype))
         dx = torch.empty_like(x)
-        dwb = torch.zeros(2, C, device=x.device, dtype=_f32)
+        dwb = torch.zeros(_LN_COPIES, 2, C, device=x.device, dtype=_f32)
         PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}{" +res" if dres is not None else ""}]',
                      (2 + (dres is not None)) * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
-            hip.lib().ge_layernorm_bwd_res(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
-                                           hip.ptr(rstd), hip.ptr(dres), hip.ptr(dx), hip.ptr(dwb[0]), hip.ptr(dwb[1]), rows, C, hip.stream()),
-            'ge_layernorm_bwd_res'))
+            hip.lib().ge_layernorm_bwd_multi(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
+                                             hip.ptr(rstd), hip.ptr(dres), hip.ptr(dx), hip.ptr(dwb), _LN_COPIES, rows, C, hip.stream()),
+            'ge_layernorm_bwd_multi'))
+        dwb = dwb.sum(0)
         return dx, dwb[0], dwb[1], None, None
 
 

@@ -186,6 +186,11 @@ int ge_layernorm_bwd(const void* dy, int y_dtype, const void* x, int x_dtype, co
  * block (depthformer_swin.py:396-472: x + attn(LN x)) x feeds the LayerNorm AND the residual; this removes autograd's separate add. */
 int ge_layernorm_bwd_res(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                          const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int C, void* stream);
+/* The same with the d_gamma / d_beta column sums spread over `copies` accumulators (same-address fp32 atomics serialise in L2): dgb =
+ * [copies][2][C] floats, zero-filled by the caller, who also sums the copies: d_gamma = sum_k dgb[k][0][:], d_beta = sum_k dgb[k][1][:].
+ * 1 <= copies <= 64. */
+int ge_layernorm_bwd_multi(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                           const float* rstd, const void* dres, void* dx, float* dgb, int copies, long rows, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual connection with per-sample stochastic depth: out[b, :] = identity[b, :] + branch[b, :] * scale[b]
