@@ -972,8 +972,9 @@ extern "C" int ge_msda_bwd_timing_read(int stage, double* total_ms, long* launch
 
 static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc,
                          const float* attw, const void* d_out, float* d_value, float* d_loc, float* d_attw, void* workspace,
-                         size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream, const MsdaEmit* em) {
-  if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || (!em && (!d_loc || !d_attw))) return GE_ERR_BAD_ARG;
+                         size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream, const MsdaEmit* em,
+                         bool value_only = false) {
+  if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || (!em && !value_only && (!d_loc || !d_attw))) return GE_ERR_BAD_ARG;
   if (B < 0 || Nv <= 0 || Nq < 0 || nH <= 0 || P <= 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
@@ -996,7 +997,7 @@ static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* qu
   const long seg_ints = (long)B * nH * pl.R * pl.ntiles;
   const bool binned = workspace && pl.ok && workspace_bytes >= msda_ws_layout(pl.nbins, seg_ints, pl.max_entries, nullptr, nullptr);
   if (!binned) {
-    if (em) return GE_ERR_UNSUPPORTED;                        // the raw-gradient variant exists on the workspace path only
+    if (em || value_only) return GE_ERR_UNSUPPORTED;          // the raw-gradient / value-only variants exist on the workspace path only
     if (dtype == GE_F32) MSDA_BWD_P(float, true); else MSDA_BWD_P(bf16_t, true);
     GE_LAUNCH_CHECK();
     return GE_OK;
@@ -1007,7 +1008,9 @@ static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* qu
   hipEvent_t* ev = nullptr;
   { std::lock_guard<std::mutex> lk(g_msda_mu); if (g_msda_timing) ev = evs; }
   msda_mark(ev, 0, s);
-  if (em) {
+  if (value_only) {
+    // d_loc / d_attw come from ge_msda_bwd_lw_mm: only the binned d_value scatter runs here
+  } else if (em) {
     if (L != 4 || P != 8) return GE_ERR_UNSUPPORTED;
     const unsigned lblocks = msda_grid(n_groups, dtype == GE_BF16 ? 32 : 16);
     const bool hm = (g_msda_mode & 8) != 0;
@@ -1071,6 +1074,14 @@ extern "C" int ge_msda_bwd(const void* value, const int* spatial_hw, const int* 
                            size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
   return msda_bwd_impl(value, spatial_hw, query_hw, n_qseg, loc, attw, d_out, d_value, d_loc, d_attw, workspace, workspace_bytes, B, Nv, Nq,
                        nH, L, P, dtype, stream, nullptr);
+}
+
+// d_value only (count / scan / fill / drain on the caller's workspace): the d_loc / d_attw half is ge_msda_bwd_lw_mm's
+extern "C" int ge_msda_bwd_value(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out,
+                                 float* d_value, void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P,
+                                 int dtype, void* stream) {
+  return msda_bwd_impl(value, spatial_hw, nullptr, 0, loc, attw, d_out, d_value, nullptr, nullptr, workspace, workspace_bytes, B, Nv, Nq,
+                       nH, L, P, dtype, stream, nullptr, true);
 }
 
 // ============================================================================ sampling-location / weight preparation
@@ -1313,6 +1324,22 @@ extern "C" int ge_msda_bwd_raw(const void* value, const int* spatial_hw, const i
   e = msda_levels(spatial_hw, L, Nv, lv);
   if (e) return e;
   const long rows = (long)B * Nq;
+  if (rows == 0) return GE_OK;
+  const unsigned blocks = ge_blocks(rows * 4, 256, 1 << 20);
+  if (dtype == GE_F32) msda_dref_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)d_off_raw, off_ld, lv, d_ref, rows, nH);
+  else msda_dref_k<bf16_t><<<blocks, 256, 0, ge_stream(stream)>>>((const bf16_t*)d_off_raw, off_ld, lv, d_ref, rows, nH);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+// d_ref (B*Nq, L, 2) f32 = sum over heads and points of d_loc, rebuilt from the emitted d_off_raw = d_loc / (W_l, H_l) (L == 4, P == 8)
+extern "C" int ge_msda_dref(const void* d_off_raw, long off_ld, const int* spatial_hw, float* d_ref, long rows, int nH, int L, int P, int dtype,
+                            void* stream) {
+  if (!d_off_raw || !spatial_hw || !d_ref || rows < 0 || nH <= 0) return GE_ERR_BAD_ARG;
+  if (L != 4 || P != 8 || (dtype != GE_F32 && dtype != GE_BF16)) return GE_ERR_UNSUPPORTED;
+  MsdaLevels lv;
+  int e = prep_levels(spatial_hw, L, lv);
+  if (e) return e;
   if (rows == 0) return GE_OK;
   const unsigned blocks = ge_blocks(rows * 4, 256, 1 << 20);
   if (dtype == GE_F32) msda_dref_k<float><<<blocks, 256, 0, ge_stream(stream)>>>((const float*)d_off_raw, off_ld, lv, d_ref, rows, nH);

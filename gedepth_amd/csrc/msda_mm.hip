@@ -1,0 +1,673 @@
+// Deformable attention as matrix products on wave-private LDS windows (gfx950, bf16 storage).
+// Same op as msda_fwd_k / msda_fwd_win_k (mmcv MultiScaleDeformableAttention.forward from the raw projection outputs: view ->
+// softmax over L*P -> ref + off / (W_l, H_l) -> bilinear sampling; reference call sites depth/models/necks/hahi.py:279-289,316-325),
+// third decomposition.
+//
+// Why: the gather kernels spend ~120 VALU + 4 row gathers per sampling point and 8-lane group and sit at the L2 -> L1 row-gather rate
+// (103 GB of 16-byte-per-lane gathers per cross-attention launch).  But for a TILE of 32 queries whose sampling points
+// land in a compact window of a level (K value rows), the sampling IS a contraction
+//
+//     out[q, ch] = sum_r C[q, r] * V[r, ch]          q: 32 queries, r: K window rows, ch: 64 channels of the head
+//
+// with C the 32 x K image of bilinear-times-attention coefficients (<= 32 non-zeros per row and level).  One
+// v_mfma_f32_32x32x16_bf16 takes 16 window rows x 32 channels for all 32 queries; the per-point work shrinks to the tap arithmetic
+// (done ONCE per point by the lane that owns it, not by 8 lanes) plus four 2-byte LDS read-modify-writes that drop the
+// coefficients into C.  The value rows of the window cross L2 -> LDS once per tile (K x 128 B) instead of once per tap.
+//
+//   wave          = (image, head, tile of 32 queries in the caller's ORDER) — no workgroup cooperation, no barriers
+//   lane          = (query q = lane & 31, hv = lane >> 5): the 8 points of ONE level per pass; pass s handles levels (s, s + 2):
+//                   lanes 0-31 own level s, lanes 32-63 level s + 2, and the two windows are CONCATENATED along K into one
+//                   coefficient image — a lane's row q is touched by its own points only (no atomics, no cross-lane collisions:
+//                   the two lanes of a query write disjoint column ranges), and no MFMA work is duplicated
+//   window        = bounding box of the in-map taps of the 32 x 8 points of a (tile, head, level), found with two packed 16-bit
+//                   min / max butterflies per half wave; windows wider than the image (CAP columns) are walked in chunks (the
+//                   scatter is predicated on the chunk), so correctness never depends on locality — only speed does
+//   coherence     = the caller passes the query ORDER (a permutation): 2-D tiles of the token maps for the self-attention, the
+//                   queries sorted by the cell of their (content-independent) reference point for the cross-attention
+//                   (hahi.py:294-302); the kernel reads / writes rows through it, so the sort costs no extra pass
+//   B operand     = value rows parked [row][channel] (gathered 8 rows x 128 B per instruction) and read with the transposing LDS
+//                   read ds_read_b64_tr_b16, the layout of msda_drain_mfma.hip
+// Numerics: coefficients are accumulated in the bf16 image (each add rounds to bf16: 2^-9 relative, the rounding class of the
+// window kernel's bf16 tap weights), products exact, sums fp32, locations fp32 in mmcv's own arithmetic (IEEE
+// division: the kink decisions of floor() match the gather kernels bit for bit).  The exact-fp32 parity path stays on the gather kernels.
+#include "msda.h"
+#include <limits.h>
+#include <algorithm>
+
+typedef __bf16 mm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mm_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 mm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mm_f32x16 __attribute__((ext_vector_type(16)));
+typedef short mm_s16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef MM_CAP
+#define MM_CAP 64                        // columns of the coefficient image = value rows staged per chunk (multiple of 16)
+#endif
+#define MM_HALF (MM_CAP * 32 + 32)       // bf16 elements of one channel-half image of the stage: [rows][32 channels] + 64 B skew
+#define MM_STAGE (2 * MM_HALF)
+#define MM_IMG ((MM_CAP + 4) * 32)       // coefficient image, TRANSPOSED: [window row k][32 queries] bf16 (+ 4 dump rows), see the kernel
+#ifndef MM_WAVES
+#define MM_WAVES 2                       // occupancy target per SIMD (registers); LDS allows 160 KB / (image + stage) per CU
+#endif
+#ifndef MM_DBUF
+#define MM_DBUF 0                        // 1: two stage buffers (the next chunk's LDS-DMA runs under this chunk's MFMAs); measured: the
+                                         // LDS it costs (7 instead of 8 waves per CU) loses more than the overlap wins on the cross-attention
+#endif
+#ifndef MM_ATOMIC
+#define MM_ATOMIC 0                      // 1: coefficients dropped with ds_pk_add_bf16 instead of read-modify-write
+#endif
+#ifndef MM_DIAG
+#define MM_DIAG 0                        // measurement aid: 1 no gathers, 2 no scatter, 4 no MFMA, 8 no output stores
+#endif
+#define MM_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+__device__ __forceinline__ bf16_t mm_bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }   // v_cvt_pk_bf16_f32, RNE
+
+// n / d for a bf16-valued n and an integer-valued d <= 8191, given r = RN(1 / d): see mm_taps
+__device__ __forceinline__ float mm_div(float n, float d, float r) {
+  const float q0 = n * r;
+  return __builtin_fmaf(__builtin_fmaf(-q0, d, n), r, q0);
+}
+
+struct MmArgs {
+  const bf16_t* value; MsdaLevels lv;
+  const bf16_t* off; long off_ld; const bf16_t* logit; long logit_ld;       // (B*Nq, ld) rows; columns (head, level, point[, xy])
+  const float* ref; long ref_sb, ref_sq, ref_sl;                              // reference points (B, Nq, L, 2), element strides
+  const int* order;                                                           // query order (Nq) or NULL = identity
+  bf16_t* out; float* loc_out; float* attw_out;                               // loc_out / attw_out may be NULL
+  int B, Nv, Nq, nH, ntiles;
+};
+
+// packed (x, y) 16-bit min / max over the 32 lanes of a half wave on the DPP network (row_shr 1, 2, 4, 8 inside the 16-lane rows, then
+// row_bcast:15 into rows 1 and 3): lanes 31 and 63 end up with their halves' results.  No LDS round trips (ds_bpermute: ~100 cycles each).
+template <bool MAXOP> __device__ __forceinline__ int mm_pk(int a, int b) {
+  const mm_s16x2 x = __builtin_bit_cast(mm_s16x2, a), y = __builtin_bit_cast(mm_s16x2, b);
+  return __builtin_bit_cast(int, MAXOP ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
+}
+template <bool MAXOP> __device__ __forceinline__ int mm_half_reduce(int v) {
+  v = mm_pk<MAXOP>(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  v = mm_pk<MAXOP>(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+  v = mm_pk<MAXOP>(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+  v = mm_pk<MAXOP>(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+  v = mm_pk<MAXOP>(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  return v;
+}
+
+// Per-lane state of the 8 points of one (query, head, level): window row of corner 00 with the +1 column / +1 row flags, and the four
+// factor weights (x weights carry the attention weight; masked corners are zero).
+typedef _Float16 mm_f16x2 __attribute__((ext_vector_type(2)));
+struct MmTaps {
+  int pk[8];                    // before the box is known: xa | ya << 15; after: r00 (30 bits); always dx << 30 | dy << 31
+  mm_f16x2 wt[8], wb[8];        // the four corner coefficients (bilinear x attention weight; masked corners zero) as f16 pairs:
+};                              // (w00, w01), (w10, w11) — 2^-11 relative, below the bf16 rounding of the image they are added into
+
+// Softmax over the 32 logits of (query, head): the lane holds the 16 of its two levels, the partner lane (lane ^ 32) the rest.
+__device__ __forceinline__ void mm_softmax(const MmArgs& a, long row, int head, int hv, bool qok, float w[2][8]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const uint4 t = *(const uint4*)(a.logit + row * a.logit_ld + head * 32 + (s + 2 * hv) * 8);
+    const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[s][2 * i] = __uint_as_float(u[i] << 16); w[s][2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(m, w[s][i]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w[s][i] = __expf(w[s][i] - m); sum += w[s][i]; }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = qok ? 1.f / sum : 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[s][i] *= inv;
+}
+
+// Tap geometry of the lane's 8 points of level `lvl` (pixel sizes Wl x Hl) from the raw offsets u[8] (bf16 pairs) and the reference
+// point.  Returns the packed box contributions: bmin = (min ya << 16 | min xa), bmax = (max yb << 16 | max xb) over the in-map points
+// (INT16 extremes when there are none).
+template <bool LOC>
+__device__ __forceinline__ void mm_taps(const MmArgs& a, const uint32_t* u, float rx, float ry, long row, int head, int lvl, int Wl, int Hl,
+                                        bool qok, const float* aw, MmTaps& tp, int& bmin, int& bmax) {
+  const float fW = (float)Wl, fH = (float)Hl;
+  const float rW = 1.f / fW, rH = 1.f / fH;                               // correctly rounded (IEEE division), once per lane and level
+  float* lp = (LOC && qok) ? a.loc_out + ((row * a.nH + head) * 32 + lvl * 8) * 2 : nullptr;
+  int xmn = 32767, ymn = 32767, xmx = -32768, ymx = -32768;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const float ox = __uint_as_float(u[p] << 16), oy = __uint_as_float(u[p] & 0xffff0000u);
+    // mmcv's arithmetic to the bit (`off / W` as msda_prep_fwd_k computes it): at initialisation the self-attention samples EXACT
+    // pixel positions, where floor() — i.e. which one-sided derivative the offsets get — is decided by the last bit of the location.
+    // The quotient is formed as q0 = off * RN(1 / W), q = fma(fma(-q0, W, off), RN(1 / W), q0): correctly rounded (Markstein), and
+    // bit-identical to IEEE division for EVERY bf16 offset and every W <= 8191 (exhaustive check: tools/ubench/msda_mm/divcheck.c) at 3
+    // instead of ~10 instructions
+    const float lx = rx + mm_div(ox, fW, rW), ly = ry + mm_div(oy, fH, rH);
+    if (LOC && lp) *(float2*)(lp + 2 * p) = make_float2(lx, ly);
+    const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;                 // grid_sample, align_corners=False
+    const bool in = qok && y > -1.f && x > -1.f && y < fH && x < fW;     // NaN-safe
+    const float xc = fminf(fmaxf(x, -1.f), fW), yc = fminf(fmaxf(y, -1.f), fH);
+    const float xf = floorf(xc), yf = floorf(yc);
+    const int x0 = (int)xf, y0 = (int)yf;
+    const float ax = xc - xf, ay = yc - yf;
+    const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+    const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+    const float wgt = in ? aw[p] : 0.f;
+    const float wxa = x0 >= 0 ? (1.f - ax) * wgt : 0.f, wxb = x0 + 1 < Wl ? ax * wgt : 0.f;
+    const float wya = y0 >= 0 ? 1.f - ay : 0.f, wyb = y0 + 1 < Hl ? ay : 0.f;
+    tp.wt[p] = __builtin_bit_cast(mm_f16x2, __builtin_amdgcn_cvt_pkrtz(wya * wxa, wya * wxb));
+    tp.wb[p] = __builtin_bit_cast(mm_f16x2, __builtin_amdgcn_cvt_pkrtz(wyb * wxa, wyb * wxb));
+    tp.pk[p] = xa | (ya << 15) | ((xb - xa) << 30) | ((yb - ya) << 31);      // xa, ya < 2^15 (launcher)
+    if (in) { xmn = min(xmn, xa); xmx = max(xmx, xb); ymn = min(ymn, ya); ymx = max(ymx, yb); }
+    if (p & 1) __builtin_amdgcn_sched_barrier(0);                        // two points in flight, not eight: ~15 live temporaries per point
+  }
+  bmin = (ymn << 16) | (xmn & 0xffff);
+  bmax = (ymx << 16) | (xmx & 0xffff);
+}
+
+// Window geometry of the two levels of a pass (wave-uniform) and the gather of one band of its value rows.
+struct MmWin {
+  int xminA, yminA, bwA, KA, WA, xminB, yminB, bwB, KB, WB, Ktot;
+  float ibwA, ibwB;
+  int startA, startB;                       // first value row of the two levels
+  const bf16_t* vb;                         // value rows of (image, head): + row * nH * 64
+};
+// Stage the value rows [c0, c0 + 16 * n16) of the concatenated window into LDS with the LDS-DMA (global_load_lds_dwordx4: no staging
+// registers; destination = wave-uniform base + lane * 16 bytes).  One instruction moves 16 rows x 64 bytes of ONE channel half: lane ->
+// (row = lane / 4, 16-byte piece = lane % 4), which is exactly a 1 KB run of the stage's [half][row][32 channels] image.  Rows past the
+// window read a row that exists (their coefficient columns are zero).
+__device__ __forceinline__ void mm_stage_rows(const MmWin& w, int c0, int n16, int lane, int nh64, bf16_t* stage) {
+  const int piece = (lane & 3) * 8;
+  for (int j = 0; j < n16; ++j) {
+    const int rr = min(c0 + j * 16 + (lane >> 2), w.Ktot - 1);
+    const bool inA = rr < w.KA;
+    const int t = inA ? rr : rr - w.KA;
+    const int bw = inA ? w.bwA : w.bwB;
+    const int ry = (int)(((float)t + 0.5f) * (inA ? w.ibwA : w.ibwB));
+    const int rx = t - mul24(ry, bw);
+    const int pix = inA ? mul24(w.yminA + ry, w.WA) + w.xminA + rx + w.startA : mul24(w.yminB + ry, w.WB) + w.xminB + rx + w.startB;
+    const bf16_t* src = w.vb + (uint32_t)(mul24(pix, nh64) + piece);      // uniform base + 32-bit element offset (launcher: < 2^31)
+    if (!(MM_DIAG & 1)) {
+      __builtin_amdgcn_global_load_lds(src, MM_LDS_PTR(void, stage + j * 16 * 32), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src + 32, MM_LDS_PTR(void, stage + MM_HALF + j * 16 * 32), 16, 0, 0);
+    }
+  }
+}
+
+// The coefficient image is kept k-major ([k][q], 64-byte rows): the scatter of a tile whose points land on the same window row (the
+// common case: neighbouring queries, equal offsets) then touches 32 consecutive bf16 — conflict-free — where a q-major image with
+// 16-byte-aligned rows puts the 32 lanes on 8 banks (measured: the 4-way conflicts made the scatter the whole kernel's bound).  The A
+// operand (8 consecutive k of one query per lane) comes back through the same transposing read as the B operand.
+template <bool LOC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVES, MM_WAVES))) msda_mm_fwd_k(MmArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t cimg[MM_IMG];
+  __shared__ __attribute__((aligned(16))) bf16_t stage2[(1 + MM_DBUF) * MM_STAGE];   // MM_DBUF: the next chunk's LDS-DMA runs under this one's MFMAs
+  const int nh64 = a.nH * 64;
+  const long total = (long)a.B * a.nH * a.ntiles;
+  // XCD x (= blockIdx % 8) walks the x-th contiguous eighth of the (image, head, tile) list: what it has in flight samples one
+  // head of one image (its 4 MB L2 ~ the 4.2 MB value slab of an (image, head) at the KITTI shape)
+  const int xcd = blockIdx.x % MSDA_XCDS, jx = blockIdx.x / MSDA_XCDS, nx = gridDim.x / MSDA_XCDS;
+  const long lo = total * xcd / MSDA_XCDS, hi = total * (xcd + 1) / MSDA_XCDS;
+  for (long item = lo + jx; item < hi; item += nx) {
+    // the lane id is laundered per item: otherwise every lane-derived address / index (~50 VGPRs of them) is hoisted out of the
+    // persistent loop as loop-invariant and pins the kernel at 2 waves per SIMD
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const int q = lane & 31, hv = lane >> 5;
+    const int sub8 = lane & 7, row8 = lane >> 3;
+    const int tr_row = (lane >> 5) * 8 + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    const int tile = (int)(item % a.ntiles);
+    const int bh = (int)(item / a.ntiles);
+    const int head = bh % a.nH, b = bh / a.nH;
+    const int qi = tile * 32 + q;
+    const bool qok = qi < a.Nq;
+    const int qsafe = qok ? qi : tile * 32;                               // a query that exists (weights are zeroed)
+    const int qq = a.order ? a.order[qsafe] : qsafe;
+    const long row = (long)b * a.Nq + qq;
+    const bf16_t* op = a.off + row * a.off_ld + head * 64 + (2 * hv) * 16;
+    const float* rp = a.ref + (long)b * a.ref_sb + (long)qq * a.ref_sq + (long)(2 * hv) * a.ref_sl;
+    uint4 o0 = *(const uint4*)op, o1 = *(const uint4*)(op + 8);
+    float rx = rp[0], ry = rp[1];
+    float aw[2][8];
+    mm_softmax(a, row, head, hv, qok, aw);
+    mm_f32x16 acc0 = 0.f, acc1 = 0.f;
+    const bf16_t* vb = a.value + ((long)b * a.Nv * a.nH + head) * 64;
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      const int lvl = s + 2 * hv;
+      MmWin w;
+      w.WA = a.lv.W[s]; w.WB = a.lv.W[s + 2];
+      const int HA = a.lv.H[s], HB = a.lv.H[s + 2];
+      const int Wl = hv ? w.WB : w.WA, Hl = hv ? HB : HA;
+      MmTaps tp;
+      int bmin, bmax;
+      {
+        const uint32_t u[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        float awl[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) awl[p] = s ? aw[1][p] : aw[0][p];
+        mm_taps<LOC>(a, u, rx, ry, row, head, lvl, Wl, Hl, qok, awl, tp, bmin, bmax);
+        if (LOC && qok) {
+          float* ap = a.attw_out + (row * a.nH + head) * 32 + lvl * 8;
+          *(float4*)ap = make_float4(awl[0], awl[1], awl[2], awl[3]);
+          *(float4*)(ap + 4) = make_float4(awl[4], awl[5], awl[6], awl[7]);
+        }
+        if (s == 0) {                                                     // the second pass's raw offsets: in flight during the first
+          o0 = *(const uint4*)(op + 16); o1 = *(const uint4*)(op + 24);
+          rx = rp[a.ref_sl]; ry = rp[a.ref_sl + 1];
+        }
+      }
+      bmin = mm_half_reduce<false>(bmin); bmax = mm_half_reduce<true>(bmax);
+      // box of each half (wave-uniform scalars): lanes 31 and 63 hold their halves' results
+      const int mnA = __builtin_amdgcn_readlane(bmin, 31), mxA = __builtin_amdgcn_readlane(bmax, 31);
+      const int mnB = __builtin_amdgcn_readlane(bmin, 63), mxB = __builtin_amdgcn_readlane(bmax, 63);
+      w.xminA = (short)(mnA & 0xffff); w.yminA = mnA >> 16;
+      w.xminB = (short)(mnB & 0xffff); w.yminB = mnB >> 16;
+      const int xmaxA = (short)(mxA & 0xffff), ymaxA = mxA >> 16, xmaxB = (short)(mxB & 0xffff), ymaxB = mxB >> 16;
+      const bool anyA = xmaxA >= w.xminA && ymaxA >= w.yminA, anyB = xmaxB >= w.xminB && ymaxB >= w.yminB;
+      w.bwA = anyA ? xmaxA - w.xminA + 1 : 0; w.bwB = anyB ? xmaxB - w.xminB + 1 : 0;
+      w.KA = anyA ? w.bwA * (ymaxA - w.yminA + 1) : 0; w.KB = anyB ? w.bwB * (ymaxB - w.yminB + 1) : 0;
+      w.Ktot = w.KA + w.KB;
+      if (w.Ktot == 0) continue;                                          // nothing of this tile samples these levels (uniform)
+      w.ibwA = 1.f / (float)max(w.bwA, 1); w.ibwB = 1.f / (float)max(w.bwB, 1);
+      w.startA = a.lv.start[s]; w.startB = a.lv.start[s + 2]; w.vb = vb;
+      mm_stage_rows(w, 0, (min(MM_CAP, w.Ktot) + 15) >> 4, lane, nh64, stage2);      // first chunk in flight under the index arithmetic + scatter
+      const int bw_l = hv ? w.bwB : w.bwA;
+      {   // window row of corner 00 in the concatenated K axis; points without a tap inside the map point at row 0 with zero weights
+        const int xmin = hv ? w.xminB : w.xminA, ymin = hv ? w.yminB : w.yminA, kofs = hv ? w.KA : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const bool live = (__builtin_bit_cast(uint32_t, tp.wt[p]) | __builtin_bit_cast(uint32_t, tp.wb[p])) != 0;   // any non-zero coefficient
+          const int k = tp.pk[p];
+          const int r00 = mul24(((k >> 15) & 0x7fff) - ymin, bw_l) + ((k & 0x7fff) - xmin) + kofs;
+          tp.pk[p] = live ? ((k & 0xc0000000) | r00) : 0;
+        }
+      }
+      bf16_t* crow = cimg + q;
+#pragma unroll 1
+      for (int c0 = 0, ci = 0; c0 < w.Ktot; c0 += MM_CAP, ci ^= 1) {
+        const int cols = min(MM_CAP, w.Ktot - c0);
+        const int n16 = (cols + 15) >> 4;
+        bf16_t* stage = stage2 + (MM_DBUF ? ci : 0) * MM_STAGE;
+        if (!MM_DBUF && c0) {                                             // single buffer: this chunk's rows start now, under the scatter
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          mm_stage_rows(w, c0, n16, lane, nh64, stage);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // clear the n16 * 16 rows this chunk uses: 1 KB per step
+          const uint4 z = make_uint4(0, 0, 0, 0);
+          for (int i = 0; i < n16; ++i) *(uint4*)(cimg + i * 512 + lane * 8) = z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // scatter: corner (p, c) of this lane's query -> crow[r - c0] += weight
+        if (!(MM_DIAG & 2)) {
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            // the packed state is laundered per chunk iteration: otherwise the unpacked form of all 8 points (32 weights, 32 column
+            // indices, 32 predicates) is hoisted out of the chunk loop as loop-invariant and the kernel spills
+            uint32_t k_ = (uint32_t)tp.pk[p], wt_ = __builtin_bit_cast(uint32_t, tp.wt[p]), wb_ = __builtin_bit_cast(uint32_t, tp.wb[p]);
+            asm volatile("" : "+v"(k_), "+v"(wt_), "+v"(wb_));
+            const int k = (int)k_;
+            const mm_f16x2 wt2 = __builtin_bit_cast(mm_f16x2, wt_), wb2 = __builtin_bit_cast(mm_f16x2, wb_);
+            const int r00 = (k & 0x3fffffff) - c0, dx = (k >> 30) & 1;
+            const int r10 = r00 + ((k >> 31) & bw_l);
+            const float w00 = (float)wt2[0], w01 = (float)wt2[1], w10 = (float)wb2[0], w11 = (float)wb2[1];
+            // masked corners and corners of another chunk go to one of the four dump rows behind the image (a clamped corner may alias
+            // its live neighbour: it must not be written)
+            const bool o00 = (unsigned)r00 < (unsigned)MM_CAP && w00 != 0.f, o01 = (unsigned)(r00 + dx) < (unsigned)MM_CAP && w01 != 0.f;
+            const bool o10 = (unsigned)r10 < (unsigned)MM_CAP && w10 != 0.f, o11 = (unsigned)(r10 + dx) < (unsigned)MM_CAP && w11 != 0.f;
+            if (__builtin_amdgcn_ballot_w64(o00 || o01 || o10 || o11) == 0) continue;      // no lane's point p reaches this chunk (uniform)
+            const int i00 = (o00 ? r00 : MM_CAP) * 32, i01 = (o01 ? r00 + dx : MM_CAP + 1) * 32;
+            const int i10 = (o10 ? r10 : MM_CAP + 2) * 32, i11 = (o11 ? r10 + dx : MM_CAP + 3) * 32;
+            const float v00 = bf2f(crow[i00]) + w00, v01 = bf2f(crow[i01]) + w01, v10 = bf2f(crow[i10]) + w10, v11 = bf2f(crow[i11]) + w11;
+            crow[i00] = mm_bf(v00); crow[i01] = mm_bf(v01); crow[i10] = mm_bf(v10); crow[i11] = mm_bf(v11);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this chunk's LDS-DMA has landed; earlier operand reads are done
+        if (MM_DBUF && c0 + MM_CAP < w.Ktot)                              // next chunk -> the other buffer, under this chunk's MFMAs
+          mm_stage_rows(w, c0 + MM_CAP, (min(MM_CAP, w.Ktot - c0 - MM_CAP) + 15) >> 4, lane, nh64, stage2 + (ci ^ 1) * MM_STAGE);
+        __builtin_amdgcn_wave_barrier();
+        if (!(MM_DIAG & 4)) {
+#pragma unroll 1
+          for (int ks = 0; ks < n16; ++ks) {
+            const bf16_t* pa = cimg + (ks * 16 + tr_row) * 32 + tr_col;
+            const mm_bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, pa));
+            const mm_bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, pa + 4 * 32));
+            const mm_bf16x8 A = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const bf16_t* p = stage + half * MM_HALF + (ks * 16 + tr_row) * 32 + tr_col;
+              const mm_bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, p));
+              const mm_bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, p + 4 * 32));
+              const mm_bf16x8 Bv = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+              if (half == 0) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, acc0, 0, 0, 0);
+              else acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, acc1, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // C/D layout: column = lane & 31 (channel of the half), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (query of the tile).  The tile
+    // goes through LDS ([32 queries][64 channels] bf16, 144-byte rows, in the stage's space) and leaves as 16-byte pieces:
+    // 8 lanes per 128-byte output row
+    if (!(MM_DIAG & 8)) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * hv;
+        stage2[m * 72 + (lane & 31)] = mm_bf(acc0[r]);
+        stage2[m * 72 + 32 + (lane & 31)] = mm_bf(acc1[r]);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = i * 8 + row8;
+        const int qm = __shfl(qq, m, 64);
+        const uint4 v = *(const uint4*)(stage2 + m * 72 + sub8 * 8);
+        if (tile * 32 + m < a.Nq) *(uint4*)(a.out + ((long)b * a.Nq + qm) * nh64 + head * 64 + sub8 * 8) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ d_loc / d_attw (raw gradients)
+// Backward of the sampling w.r.t. locations and attention weights, emitted as the gradient of the RAW projection outputs (mmcv's
+// view / normaliser / softmax backward folded in, as msda_bwd_lw_k<.., EMIT>).  Same decomposition as the forward: for a (tile, head,
+// level pair, chunk of window rows) the four <gradient row, value row> dot products every sampling point needs are entries of
+//
+//     S^T[r, q] = sum_ch V[r, ch] * G[q, ch]         r: window rows of the chunk, q: the 32 queries, ch: 64 channels
+//
+// 4 MFMAs per 32 window rows with the gradient rows as B fragments straight from global memory (a lane's 8 consecutive channels of
+// its query: no LDS, loaded once per tile) and the value rows as A fragments (ds_read_b128 from the LDS-DMA stage).  S^T goes to LDS
+// as [r][32 queries] fp32: the lane that owns a point reads S^T[r_corner][its q] — always its own bank — and accumulates the three
+// sums (weight, d/dx, d/dy) of its 8 points over the chunks.
+struct MmBwdArgs {
+  MmArgs f;                                   // forward inputs (out / loc_out / attw_out unused)
+  const bf16_t* gout;                         // (B, Nq, nH*64)
+  bf16_t* d_off; long d_off_ld; bf16_t* d_logit; long d_logit_ld;
+};
+#define MM_SIMG ((MM_CAP + 1) * 32)           // fp32 elements: [window row][32 queries] + one dump row
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVES, MM_WAVES))) msda_mm_bwd_lw_k(MmBwdArgs ba) {
+  __shared__ __attribute__((aligned(16))) float simg[MM_SIMG];
+  __shared__ __attribute__((aligned(16))) bf16_t stage2[(1 + MM_DBUF) * MM_STAGE];
+  const MmArgs& a = ba.f;
+  const int nh64 = a.nH * 64;
+  const long total = (long)a.B * a.nH * a.ntiles;
+  const int xcd = blockIdx.x % MSDA_XCDS, jx = blockIdx.x / MSDA_XCDS, nx = gridDim.x / MSDA_XCDS;
+  const long lo = total * xcd / MSDA_XCDS, hi = total * (xcd + 1) / MSDA_XCDS;
+  for (long item = lo + jx; item < hi; item += nx) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));                                        // see msda_mm_fwd_k
+    const int q = lane & 31, hv = lane >> 5;
+    const int tile = (int)(item % a.ntiles);
+    const int bh = (int)(item / a.ntiles);
+    const int head = bh % a.nH, b = bh / a.nH;
+    const int qi = tile * 32 + q;
+    const bool qok = qi < a.Nq;
+    const int qsafe = qok ? qi : tile * 32;
+    const int qq = a.order ? a.order[qsafe] : qsafe;
+    const long row = (long)b * a.Nq + qq;
+    const bf16_t* op = a.off + row * a.off_ld + head * 64 + (2 * hv) * 16;
+    const float* rp = a.ref + (long)b * a.ref_sb + (long)qq * a.ref_sq + (long)(2 * hv) * a.ref_sl;
+    uint4 o0 = *(const uint4*)op, o1 = *(const uint4*)(op + 8);
+    float rx = rp[0], ry = rp[1];
+    // gradient row of (query, head) as the four B fragments: channels ks * 16 + hv * 8 .. + 7
+    mm_bf16x8 G[4];
+    {
+      const bf16_t* gp = ba.gout + row * nh64 + head * 64 + hv * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) G[ks] = qok ? *(const mm_bf16x8*)(gp + ks * 16) : mm_bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    float aw[2][8];
+    mm_softmax(a, row, head, hv, qok, aw);
+    float dsum = 0.f;                                                     // sum over this lane's 16 points of attw * d_attw
+    float dav[2][8];
+    const bf16_t* vb = a.value + ((long)b * a.Nv * a.nH + head) * 64;
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      const int lvl = s + 2 * hv;
+      MmWin w;
+      w.WA = a.lv.W[s]; w.WB = a.lv.W[s + 2];
+      const int HA = a.lv.H[s], HB = a.lv.H[s + 2];
+      const int Wl = hv ? w.WB : w.WA, Hl = hv ? HB : HA;
+      int pk[8];
+      float fx[8], fy[8], awl[8];
+      int bmin, bmax;
+      {
+        const uint32_t u[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+        const float fW = (float)Wl, fH = (float)Hl;
+        const float rW = 1.f / fW, rH = 1.f / fH;
+        int xmn = 32767, ymn = 32767, xmx = -32768, ymx = -32768;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          awl[p] = s ? aw[1][p] : aw[0][p];
+          const float ox = __uint_as_float(u[p] << 16), oy = __uint_as_float(u[p] & 0xffff0000u);
+          const float lx = rx + mm_div(ox, fW, rW), ly = ry + mm_div(oy, fH, rH);     // the forward's arithmetic to the bit
+          const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+          const bool in = qok && y > -1.f && x > -1.f && y < fH && x < fW;
+          const float xc = fminf(fmaxf(x, -1.f), fW), yc = fminf(fmaxf(y, -1.f), fH);
+          const float xf = floorf(xc), yf = floorf(yc);
+          const int x0 = (int)xf, y0 = (int)yf;
+          fx[p] = xc - xf; fy[p] = yc - yf;
+          const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+          const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+          // corner masks 00, 01, 10, 11 in bits 26-29 of the second word (kept in the sign bits of fx / fy would cost precision)
+          const int m = (in && y0 >= 0 && x0 >= 0 ? 1 : 0) | (in && y0 >= 0 && x0 + 1 < Wl ? 2 : 0) | (in && y0 + 1 < Hl && x0 >= 0 ? 4 : 0) |
+                        (in && y0 + 1 < Hl && x0 + 1 < Wl ? 8 : 0);
+          pk[p] = xa | (ya << 13) | (m << 26) | ((xb - xa) << 30) | ((yb - ya) << 31);     // xa, ya < 2^13 (launcher)
+          if (in) { xmn = min(xmn, xa); xmx = max(xmx, xb); ymn = min(ymn, ya); ymx = max(ymx, yb); }
+        }
+        bmin = (ymn << 16) | (xmn & 0xffff);
+        bmax = (ymx << 16) | (xmx & 0xffff);
+        if (s == 0) {
+          o0 = *(const uint4*)(op + 16); o1 = *(const uint4*)(op + 24);
+          rx = rp[a.ref_sl]; ry = rp[a.ref_sl + 1];
+        }
+      }
+      bmin = mm_half_reduce<false>(bmin); bmax = mm_half_reduce<true>(bmax);
+      const int mnA = __builtin_amdgcn_readlane(bmin, 31), mxA = __builtin_amdgcn_readlane(bmax, 31);
+      const int mnB = __builtin_amdgcn_readlane(bmin, 63), mxB = __builtin_amdgcn_readlane(bmax, 63);
+      w.xminA = (short)(mnA & 0xffff); w.yminA = mnA >> 16;
+      w.xminB = (short)(mnB & 0xffff); w.yminB = mnB >> 16;
+      const int xmaxA = (short)(mxA & 0xffff), ymaxA = mxA >> 16, xmaxB = (short)(mxB & 0xffff), ymaxB = mxB >> 16;
+      const bool anyA = xmaxA >= w.xminA && ymaxA >= w.yminA, anyB = xmaxB >= w.xminB && ymaxB >= w.yminB;
+      w.bwA = anyA ? xmaxA - w.xminA + 1 : 0; w.bwB = anyB ? xmaxB - w.xminB + 1 : 0;
+      w.KA = anyA ? w.bwA * (ymaxA - w.yminA + 1) : 0; w.KB = anyB ? w.bwB * (ymaxB - w.yminB + 1) : 0;
+      w.Ktot = w.KA + w.KB;
+      float sv[8], sx[8], sy[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) { sv[p] = 0.f; sx[p] = 0.f; sy[p] = 0.f; }
+      if (w.Ktot > 0) {                                                   // uniform
+        w.ibwA = 1.f / (float)max(w.bwA, 1); w.ibwB = 1.f / (float)max(w.bwB, 1);
+        w.startA = a.lv.start[s]; w.startB = a.lv.start[s + 2]; w.vb = vb;
+        mm_stage_rows(w, 0, (min(MM_CAP, w.Ktot) + 15) >> 4, lane, nh64, stage2);
+        const int bw_l = hv ? w.bwB : w.bwA;
+        {
+          const int xmin = hv ? w.xminB : w.xminA, ymin = hv ? w.yminB : w.yminA, kofs = hv ? w.KA : 0;
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            const int k = pk[p];
+            const bool live = (k & (15 << 26)) != 0;
+            const int r00 = mul24(((k >> 13) & 0x1fff) - ymin, bw_l) + ((k & 0x1fff) - xmin) + kofs;
+            pk[p] = live ? ((k & 0xfc000000) | r00) : 0;                  // r00 < 2^26 (launcher: Nv < 2^26)
+          }
+        }
+#pragma unroll 1
+        for (int c0 = 0, ci = 0; c0 < w.Ktot; c0 += MM_CAP, ci ^= 1) {
+          const int cols = min(MM_CAP, w.Ktot - c0);
+          const int n16 = (cols + 15) >> 4;
+          bf16_t* stage = stage2 + (MM_DBUF ? ci : 0) * MM_STAGE;
+          if (!MM_DBUF && c0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mm_stage_rows(w, c0, n16, lane, nh64, stage);
+          }
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this chunk has landed; the previous chunk's reads are done
+          if (MM_DBUF && c0 + MM_CAP < w.Ktot)
+            mm_stage_rows(w, c0 + MM_CAP, (min(MM_CAP, w.Ktot - c0 - MM_CAP) + 15) >> 4, lane, nh64, stage2 + (ci ^ 1) * MM_STAGE);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+          for (int mb = 0; mb < (n16 + 1) >> 1; ++mb) {
+            mm_f32x16 acc = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const mm_bf16x8 A = *(const mm_bf16x8*)(stage + (ks >> 1) * MM_HALF + (mb * 32 + q) * 32 + (ks & 1) * 16 + hv * 8);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, G[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) simg[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv) * 32 + q] = acc[r];
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            uint32_t k_ = (uint32_t)pk[p];
+            asm volatile("" : "+v"(k_));                                  // keep the unpacked form out of the chunk loop's preheader
+            const int k = (int)k_;
+            const int r00 = (k & 0x03ffffff) - c0, dx = (k >> 30) & 1;
+            const int r10 = r00 + ((k >> 31) & bw_l);
+            const bool o00 = (unsigned)r00 < (unsigned)MM_CAP && (k & (1 << 26)), o01 = (unsigned)(r00 + dx) < (unsigned)MM_CAP && (k & (2 << 26));
+            const bool o10 = (unsigned)r10 < (unsigned)MM_CAP && (k & (4 << 26)), o11 = (unsigned)(r10 + dx) < (unsigned)MM_CAP && (k & (8 << 26));
+            if (__builtin_amdgcn_ballot_w64(o00 || o01 || o10 || o11) == 0) continue;
+            float d00 = simg[(o00 ? r00 : MM_CAP) * 32 + q], d01 = simg[(o01 ? r00 + dx : MM_CAP) * 32 + q];
+            float d10 = simg[(o10 ? r10 : MM_CAP) * 32 + q], d11 = simg[(o11 ? r10 + dx : MM_CAP) * 32 + q];
+            d00 = o00 ? d00 : 0.f; d01 = o01 ? d01 : 0.f; d10 = o10 ? d10 : 0.f; d11 = o11 ? d11 : 0.f;
+            const float ax = fx[p], ay = fy[p], bx = 1.f - ax, by = 1.f - ay;
+            sv[p] += by * (bx * d00 + ax * d01) + ay * (bx * d10 + ax * d11);
+            sx[p] += by * (d01 - d00) + ay * (d11 - d10);
+            sy[p] += bx * (d10 - d00) + ax * (d11 - d01);
+          }
+        }
+      }
+      // d_off = d_loc / (W, H) with d_loc = s * (weight * (W, H)): the level's 8 (x, y) pairs leave as one 32-byte run
+      {
+        uint32_t pr[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          pr[p] = (uint32_t)mm_bf(sx[p] * awl[p]) | ((uint32_t)mm_bf(sy[p] * awl[p]) << 16);
+          dsum += awl[p] * sv[p];
+          if (s == 0) dav[0][p] = sv[p]; else dav[1][p] = sv[p];
+        }
+        if (qok) {
+          bf16_t* dp = ba.d_off + row * ba.d_off_ld + head * 64 + lvl * 16;
+          *(uint4*)dp = make_uint4(pr[0], pr[1], pr[2], pr[3]);
+          *(uint4*)(dp + 8) = make_uint4(pr[4], pr[5], pr[6], pr[7]);
+        }
+      }
+    }
+    // softmax backward over the 32 points of (query, head): d_logit = attw * (d_attw - sum attw * d_attw)
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (qok) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t pr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          pr[i] = (uint32_t)mm_bf(aw[s][2 * i] * (dav[s][2 * i] - dsum)) | ((uint32_t)mm_bf(aw[s][2 * i + 1] * (dav[s][2 * i + 1] - dsum)) << 16);
+        *(uint4*)(ba.d_logit + row * ba.d_logit_ld + head * 32 + (s + 2 * hv) * 8) = make_uint4(pr[0], pr[1], pr[2], pr[3]);
+      }
+    }
+  }
+}
+
+int msda_mm_supported(int B, int Nq, int Nv, int nH, int L, int P, int dtype, const MsdaLevels& lv) {
+  if (dtype != GE_BF16 || L != 4 || P != 8 || nH < 1) return 0;
+  for (int l = 0; l < L; ++l) if (lv.W[l] > 8191 || lv.H[l] > 8191) return 0;      // 13-bit tap coordinates in the packed point state
+  if (Nv >= (1 << 26)) return 0;
+  if ((long)Nv * nH * 64 >= (1L << 31) || (long)B * Nq * nH * L * P >= (1L << 31)) return 0;
+  return 1;
+}
+
+int msda_mm_fwd_launch(const MmArgs& a0, hipStream_t s) {
+  MmArgs a = a0;
+  a.ntiles = (a.Nq + 31) / 32;
+  const long total = (long)a.B * a.nH * a.ntiles;
+  if (total <= 0) return GE_OK;
+  // persistent single-wave workgroups: exactly what is resident at once (a second round of workgroups would start when the first ends)
+  static int per_cu = 0, n_cu = 0;
+  if (!per_cu) {
+    int dev = 0, v = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return GE_ERR_UNSUPPORTED;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, msda_mm_fwd_k<false>, 64, 0) != hipSuccess || v < 1) v = 8;
+    n_cu = pr.multiProcessorCount; per_cu = v;
+  }
+  long blocks = std::min(total, (long)n_cu * per_cu);
+  blocks = std::max(blocks / MSDA_XCDS * MSDA_XCDS, (long)MSDA_XCDS);
+  if (a.loc_out) msda_mm_fwd_k<true><<<(unsigned)blocks, 64, 0, s>>>(a);
+  else msda_mm_fwd_k<false><<<(unsigned)blocks, 64, 0, s>>>(a);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+int msda_mm_bwd_lw_launch(const MmBwdArgs& b0, hipStream_t s) {
+  MmBwdArgs ba = b0;
+  ba.f.ntiles = (ba.f.Nq + 31) / 32;
+  const long total = (long)ba.f.B * ba.f.nH * ba.f.ntiles;
+  if (total <= 0) return GE_OK;
+  static int per_cu = 0, n_cu = 0;
+  if (!per_cu) {
+    int dev = 0, v = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return GE_ERR_UNSUPPORTED;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, msda_mm_bwd_lw_k, 64, 0) != hipSuccess || v < 1) v = 8;
+    n_cu = pr.multiProcessorCount; per_cu = v;
+  }
+  long blocks = std::min(total, (long)n_cu * per_cu);
+  blocks = std::max(blocks / MSDA_XCDS * MSDA_XCDS, (long)MSDA_XCDS);
+  msda_mm_bwd_lw_k<<<(unsigned)blocks, 64, 0, s>>>(ba);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+extern "C" int ge_msda_mm_supported(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int dtype) {
+  MsdaLevels lv;
+  if (!spatial_hw || msda_levels(spatial_hw, L, Nv, lv)) return 0;
+  return msda_mm_supported(B, Nq, Nv, nH, L, P, dtype, lv);
+}
+
+extern "C" int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                              long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, float* loc,
+                              float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !out || B < 0 || Nq < 0 || (loc == nullptr) != (attw == nullptr)) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  if (!msda_mm_supported(B, Nq, Nv, nH, L, P, dtype, lv)) return GE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)off_raw | (uintptr_t)logit_raw) & 15) || off_ld % 8 || logit_ld % 8) return GE_ERR_BAD_ARG;
+  MmArgs a;
+  a.value = (const bf16_t*)value; a.lv = lv;
+  a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
+  a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
+  a.out = (bf16_t*)out; a.loc_out = loc; a.attw_out = attw;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0;
+  return msda_mm_fwd_launch(a, ge_stream(stream));
+}
+
+// d_off_raw / d_logit_raw (same layout and type as off_raw / logit_raw, fully written) from the gradient of the output; d_value is NOT
+// produced here (ge_msda_bwd_value_* / the binned path).
+extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                                 long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order,
+                                 const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, int B, int Nv,
+                                 int Nq, int nH, int L, int P, int dtype, void* stream) {
+  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_off_raw || !d_logit_raw || B < 0 || Nq < 0) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  if (!msda_mm_supported(B, Nq, Nv, nH, L, P, dtype, lv)) return GE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)off_raw | (uintptr_t)logit_raw | (uintptr_t)d_off_raw | (uintptr_t)d_logit_raw | (uintptr_t)d_out) & 15) || off_ld % 8 || logit_ld % 8 ||
+      d_off_ld % 8 || d_logit_ld % 8)
+    return GE_ERR_BAD_ARG;
+  MmBwdArgs ba;
+  MmArgs& a = ba.f;
+  a.value = (const bf16_t*)value; a.lv = lv;
+  a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
+  a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
+  a.out = nullptr; a.loc_out = nullptr; a.attw_out = nullptr;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0;
+  ba.gout = (const bf16_t*)d_out;
+  ba.d_off = (bf16_t*)d_off_raw; ba.d_off_ld = d_off_ld; ba.d_logit = (bf16_t*)d_logit_raw; ba.d_logit_ld = d_logit_ld;
+  return msda_mm_bwd_lw_launch(ba, ge_stream(stream));
+}

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .... import kernels as K
 from ....kernels import add_rows, concat_tokens_map, ms_deform_attn_raw, residual_dropout, tokens_from_map
 from ....mmrt import bricks
 from ....mmrt.bricks import BaseModule, ConvModule, build_positional_encoding, xavier_init
@@ -50,7 +51,7 @@ class MultiScaleDeformableAttention(BaseModule):
         xavier_init(self.output_proj, distribution='uniform', bias=0.)
         self._is_init = True
 
-    def _attend(self, query, value, reference_points, spatial_shapes, key_padding_mask=None, query_shapes=None):
+    def _attend(self, query, value, reference_points, spatial_shapes, key_padding_mask=None, query_shapes=None, query_order=None):
         """query (B,Nq,C) with the positional embedding already added, value (B,Nv,C) -> output_proj(sampled) (B,Nq,C).
 
         The two query linears run as ONE GEMM on concatenated weights (their input is the same 0.4-0.8 GB tensor), and
@@ -74,7 +75,12 @@ class MultiScaleDeformableAttention(BaseModule):
         # pixel coordinates up to ~1000 need > 8 mantissa bits); its backward returns the gradient of `raw` directly
         if raw.dtype != value.dtype:
             raw = raw.to(value.dtype)
-        out = ms_deform_attn_raw(value, raw, reference_points.expand(bs, num_query, L, 2), spatial_shapes, query_shapes, nH, L, P)
+        ref = reference_points.expand(bs, num_query, L, 2)
+        if query_order is not None and 'msda_mm' not in K.DISABLED and K.msda_mm_supported(value, raw, spatial_shapes, nH, L, P):
+            # MFMA decomposition on query tiles in `query_order` (csrc/msda_mm.hip); any order gives the same result
+            out = K.ms_deform_attn_mm(value, raw, ref, spatial_shapes, query_order, nH, L, P)
+        else:
+            out = ms_deform_attn_raw(value, raw, ref, spatial_shapes, query_shapes, nH, L, P)
         return self.output_proj(out)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
@@ -99,12 +105,12 @@ class MultiScaleDeformableAttention(BaseModule):
             return residual_dropout(identity, out, self.dropout.p)
         return self.dropout(out) + identity
 
-    def forward_map(self, fmap, pos_map, value, reference_points, spatial_shapes, concat_with):
+    def forward_map(self, fmap, pos_map, value, reference_points, spatial_shapes, concat_with, query_order=None):
         """Cross-attention with a feature-map query (hahi.py:303-333): query = tokens(fmap) + pos, identity = fmap, and the
         result returned as ``torch.cat([to_map(dropout(out) + identity), concat_with], 1)``.  The two layout changes carry
         the position add, the dropout, the residual and the concat write (gedepth_amd/csrc/neck.hip)."""
         query = tokens_from_map(fmap, pos_map)
-        out = self._attend(query, value, reference_points, spatial_shapes, query_shapes=[tuple(fmap.shape[2:])])
+        out = self._attend(query, value, reference_points, spatial_shapes, query_shapes=[tuple(fmap.shape[2:])], query_order=query_order)
         p = self.dropout.p if self.training else 0.0
         return concat_tokens_map(out, concat_with, identity=fmap, tokens_first=True, p_drop=p)
 
@@ -138,6 +144,21 @@ class HAHIHeteroNeck(BaseModule):
         self.multi_att = MultiScaleDeformableAttention(**att)
         self.self_attn = MultiScaleDeformableAttention(**att)
         self._ref_cache = {}
+        self._order_cache = {}          # cross-attention query order (a speed heuristic): refreshed every ORDER_REFRESH forwards
+
+    ORDER_REFRESH = 64
+
+    def _cross_order(self, ref_xy, level0_hw):
+        """Queries sorted by the level-0 cell of their (content-independent) reference point, so that 32 consecutive queries sample
+        one compact window (csrc/msda_mm.hip).  The result of the attention does not depend on the order; the reference points move
+        slowly under training, so the sort (a dozen small launches) is redone only every ORDER_REFRESH forwards."""
+        key = (tuple(ref_xy.shape), tuple(level0_hw), str(ref_xy.device))
+        ent = self._order_cache.get(key)
+        if ent is None or ent[1] >= self.ORDER_REFRESH:
+            ent = [K.msda_ref_order(ref_xy.detach(), level0_hw), 0]
+            self._order_cache = {key: ent}
+        ent[1] += 1
+        return ent[0]
 
     def init_weights(self):
         for p in self.parameters():
@@ -200,8 +221,9 @@ class HAHIHeteroNeck(BaseModule):
                 pm = pos_map.flatten(2)[0]                                               # (C, H*W)
                 w, b = self.reference_points.weight, self.reference_points.bias
                 ref = torch.stack((torch.mv(pm.t(), w[0]), torch.mv(pm.t(), w[1])), -1).add(b).sigmoid()[None]
+            order = self._cross_order(ref[0], shapes[0]) if (conv_skip.is_cuda and src.dtype == torch.bfloat16) else None
             ref = ref[:, :, None, :].expand(bs, -1, len(shapes), 2)
-            fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv)
+            fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv, query_order=order)
         else:
             fused = torch.cat([conv_skip, feat_conv], dim=1)
         # one split (backward: ONE concatenating write of the level gradients) instead of per-level slices, whose backward

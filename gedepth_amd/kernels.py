@@ -368,6 +368,136 @@ def ms_deform_attn_raw(value, raw, reference_points, spatial_shapes, query_shape
     return _MSDeformAttnRaw.apply(value, raw, reference_points, spatial_shapes, query_shapes, int(num_heads), int(num_levels), int(num_points))
 
 
+# ---- deformable attention as MFMA contractions (csrc/msda_mm.hip): query orders + forward
+_TILE_ORDER_CACHE = {}
+
+
+def msda_tile_order(query_shapes, device, th=4, tw=8):
+    """Query order for grid queries (self-attention: the queries ARE the token maps): each (H, W) segment is cut into th x tw
+    tiles and the queries are listed tile by tile, so 32 consecutive entries are a compact 2-D patch.  int32 (Nq,), cached."""
+    key = (tuple(tuple(int(v) for v in hw) for hw in query_shapes), str(device), th, tw)
+    if key not in _TILE_ORDER_CACHE:
+        parts, start = [], 0
+        for h, w in key[0]:
+            idx = torch.arange(h * w, dtype=torch.int64).view(h, w)
+            ph, pw = (-h) % th, (-w) % tw
+            idx = torch.nn.functional.pad(idx, (0, pw, 0, ph), value=-1)
+            hh, ww = idx.shape
+            t = idx.view(hh // th, th, ww // tw, tw).permute(0, 2, 1, 3).reshape(-1)
+            parts.append(t[t >= 0] + start)
+            start += h * w
+        _TILE_ORDER_CACHE[key] = torch.cat(parts).to(torch.int32).to(device)
+    return _TILE_ORDER_CACHE[key]
+
+
+def msda_ref_order(ref_xy, level0_hw):
+    """Query order for content-independent reference points (cross-attention, hahi.py:294-302): sort the queries by the Morton
+    code of the level-0 cell (quarter-cell resolution) of their reference point.  ref_xy (Nq, 2) in [0, 1] -> int32 (Nq,)."""
+    h, w = level0_hw
+    x = (ref_xy[:, 0].float() * (4 * w)).clamp_(0, 4 * w - 1).to(torch.int64)
+    y = (ref_xy[:, 1].float() * (4 * h)).clamp_(0, 4 * h - 1).to(torch.int64)
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+    return torch.argsort((spread(y) << 1) | spread(x)).to(torch.int32)
+
+
+def msda_fwd_mm(value, raw, ref, spatial_shapes, order=None, want_loc=False, nH=8, L=4, P=8):
+    """ge_msda_fwd_mm: value (B,Nv,nH,64) bf16, raw (B,Nq,nH*L*P*3) bf16, ref (B,Nq,L,2) f32 (may be an expanded view)."""
+    value, raw = _c(value), _c(raw)
+    B, Nv, _, D = value.shape
+    _, Nq, ld = raw.shape
+    n_off = nH * L * P * 2
+    assert D == 64 and ld == n_off + nH * L * P and raw.dtype == value.dtype == torch.bfloat16
+    ref = ref.to(_f32)
+    assert ref.is_cuda and tuple(ref.shape) == (B, Nq, L, 2)
+    if ref.stride(3) != 1:
+        ref = ref.contiguous()
+    arr, _ = _levels(spatial_shapes)
+    out = torch.empty(B, Nq, nH * D, device=value.device, dtype=value.dtype)
+    loc = torch.empty(B, Nq, nH, L, P, 2, device=raw.device, dtype=_f32) if want_loc else None
+    attw = torch.empty(B, Nq, nH, L, P, device=raw.device, dtype=_f32) if want_loc else None
+    if order is not None:
+        assert order.dtype == torch.int32 and order.is_cuda and order.numel() == Nq and order.is_contiguous()
+    base = hip.ptr(raw, name='raw')
+    nbytes = value.numel() * 2 + raw.numel() * 2 + out.numel() * 2 + ((loc.numel() + attw.numel()) * 4 if want_loc else 0)
+    PROFILER.run(f'msda_fwd_mm[B{B} Nq{Nq} Nv{Nv}]', nbytes, lambda: hip.check(hip.lib().ge_msda_fwd_mm(
+        hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), base, ld, base + n_off * 2, ld, ref.data_ptr(),
+        ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(order), hip.ptr(loc), hip.ptr(attw), hip.ptr(out), B, Nv, Nq, nH, L, P,
+        hip.dtype_code(value), hip.stream()), 'ge_msda_fwd_mm'))
+    return (out, loc, attw) if want_loc else out
+
+
+class _MSDeformAttnMM(torch.autograd.Function):
+    """Deformable attention from the raw projections on the MFMA decomposition (csrc/msda_mm.hip): forward ge_msda_fwd_mm, backward
+    ge_msda_bwd_lw_mm (d_raw) + ge_msda_dref (d_ref) + the binned d_value scatter (ge_msda_bwd_value)."""
+
+    @staticmethod
+    def forward(ctx, value, raw, ref, order, spatial_shapes, nH, L, P):
+        out, loc, attw = msda_fwd_mm(value, raw, ref, spatial_shapes, order, want_loc=True, nH=nH, L=L, P=P)
+        ctx.save_for_backward(value, raw, ref, order, loc, attw)
+        ctx.meta = (tuple(tuple(int(v) for v in hw) for hw in spatial_shapes), nH, L, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        value, raw, ref, order, loc, attw = ctx.saved_tensors
+        shapes, nH, L, P = ctx.meta
+        value, raw = _c(value), _c(raw)
+        B, Nv, _, D = value.shape
+        _, Nq, ld = raw.shape
+        n_off = nH * L * P * 2
+        d_out = _c(d_out.to(value.dtype))
+        ref = ref.to(_f32)
+        if ref.stride(3) != 1:
+            ref = ref.contiguous()
+        arr, _ = _levels(shapes)
+        shapes_p = ctypes.cast(arr, ctypes.c_void_p)
+        lib = hip.lib()
+        d_raw = torch.empty(B, Nq, ld, device=value.device, dtype=raw.dtype)
+        base, dbase = hip.ptr(raw), hip.ptr(d_raw)
+        nb_lw = value.numel() * 2 + raw.numel() * 2 + d_raw.numel() * 2 + d_out.numel() * 2
+        PROFILER.run(f'msda_bwd_lw_mm[B{B} Nq{Nq} Nv{Nv}]', nb_lw, lambda: hip.check(lib.ge_msda_bwd_lw_mm(
+            hip.ptr(value), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+            hip.ptr(order), hip.ptr(d_out), dbase, ld, dbase + n_off * 2, ld, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
+            'ge_msda_bwd_lw_mm'))
+        d_ref = None
+        if ctx.needs_input_grad[2]:
+            d_ref = torch.empty(B, Nq, L, 2, device=value.device, dtype=_f32)
+            hip.check(lib.ge_msda_dref(dbase, ld, shapes_p, hip.ptr(d_ref), B * Nq, nH, L, P, hip.dtype_code(value), hip.stream()), 'ge_msda_dref')
+        d_value = None
+        if ctx.needs_input_grad[0]:
+            d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
+            ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
+            assert ws_bytes > 0, 'binned d_value path unavailable for this geometry'
+            ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8)
+            if PROFILER.on:
+                la_b = (loc.numel() + attw.numel()) * 4
+                PROFILER.add_stage_bytes((0, la_b, 0, la_b, d_out.numel() * 2 + d_value.numel() * 4))
+            PROFILER.run(f'msda_bwd_value[B{B} Nq{Nq} Nv{Nv}]', 2 * (loc.numel() + attw.numel()) * 4 + d_out.numel() * 2 + d_value.numel() * 4,
+                         lambda: hip.check(lib.ge_msda_bwd_value(hip.ptr(value), shapes_p, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
+                                                                 hip.ptr(d_value), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P,
+                                                                 hip.dtype_code(value), hip.stream()), 'ge_msda_bwd_value'))
+            d_value = d_value.to(value.dtype)
+        return d_value, d_raw, d_ref, None, None, None, None, None
+
+
+def msda_mm_supported(value, raw, spatial_shapes, nH, L, P):
+    if not (value.is_cuda and value.dtype == torch.bfloat16 and raw.dtype == torch.bfloat16 and value.shape[-1] == 64):
+        return False
+    arr, _ = _levels(spatial_shapes)
+    B, Nv = value.shape[:2]
+    return bool(hip.lib().ge_msda_mm_supported(ctypes.cast(arr, ctypes.c_void_p), B, Nv, raw.shape[1], nH, L, P, hip.GE_BF16))
+
+
+def ms_deform_attn_mm(value, raw, reference_points, spatial_shapes, order, num_heads=8, num_levels=4, num_points=8):
+    """``ms_deform_attn_raw`` on the MFMA decomposition: queries are processed in ``order`` (int32 permutation, or None)."""
+    return _MSDeformAttnMM.apply(value, raw, reference_points, order, spatial_shapes, int(num_heads), int(num_levels), int(num_points))
+
+
 # ---------------------------------------------------------------------------- channels-last helpers
 _CL = torch.channels_last
 

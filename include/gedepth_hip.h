@@ -166,6 +166,28 @@ int ge_msda_fwd_raw(const void* value, const int* spatial_hw, const int* query_h
 int ge_msda_bwd_raw(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc, const float* attw,
                     const void* d_out, float* d_value, void* d_off_raw, long off_ld, void* d_logit_raw, long logit_ld, float* d_ref,
                     void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+/* Deformable attention as MFMA contractions on wave-private LDS windows (round 4; csrc/msda_mm.hip): the same op as
+ * ge_msda_fwd_raw for bf16 storage, L == 4, P == 8, with the queries processed in the caller's ORDER — `order` (device, Nq ints, a
+ * permutation of 0..Nq-1, the same for every image; NULL = identity) lists the queries so that 32 consecutive entries sample
+ * neighbouring value rows (2-D tiles of the token maps for the self-attention, the queries sorted by the cell of their reference
+ * point for the cross-attention, depth/models/necks/hahi.py:294-302).  Results do not depend on the order, only the speed does.
+ * loc / attw: as ge_msda_fwd_raw, or both NULL (not written). */
+int ge_msda_mm_supported(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P, int dtype);
+int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                   const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, float* loc, float* attw, void* out,
+                   int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+/* Backward of ge_msda_fwd_mm in two halves: ge_msda_bwd_lw_mm emits d_off_raw / d_logit_raw (layout and type of off_raw /
+ * logit_raw, fully written; mmcv's view / normaliser / softmax backward folded in) on the same MFMA decomposition; ge_msda_bwd_value
+ * runs the binned d_value scatter of ge_msda_bwd alone (loc / attw as written by the forward, workspace of ge_msda_bwd_workspace,
+ * d_value f32 zero-filled by the caller); ge_msda_dref rebuilds d_ref (rows, L, 2) f32 from the emitted d_off_raw. */
+int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                      const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, void* d_off_raw,
+                      long d_off_ld, void* d_logit_raw, long d_logit_ld, int B, int Nv, int Nq, int nH, int L, int P, int dtype,
+                      void* stream);
+int ge_msda_bwd_value(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out, float* d_value,
+                      void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+int ge_msda_dref(const void* d_off_raw, long off_ld, const int* spatial_hw, float* d_ref, long rows, int nH, int L, int P, int dtype,
+                 void* stream);
 int ge_tokens_from_map(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
                        float p_drop, unsigned long long seed, int dtype, void* stream);
 int ge_map_from_tokens(const void* tok, long tok_bs, const void* res, long res_bs, void* map, long map_bs, int B, int C,

@@ -149,6 +149,20 @@ def test_library_exports_every_declared_symbol():
     assert hip.lib().ge_window_attn_bwd_workspace(2, 11, 35, 3) > 0
 
 
+def test_msda_mm_location_division_is_ieee_division(tmp_path):
+    """csrc/msda_mm.hip forms `offset / W` as q0 = off * RN(1/W), q = fma(fma(-q0, W, off), RN(1/W), q0).  The kink decisions of
+    floor() in the sampling kernels hang on the last bit of that quotient, so the claim "bit-identical to IEEE division" is checked
+    exhaustively on the host: every bf16 offset x every map width the kernel accepts (tools/ubench/divcheck.c, plain C with fmaf)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    exe = str(tmp_path / 'divcheck')
+    subprocess.run(['gcc', '-O2', '-ffp-contract=off', os.path.join(ROOT, 'tools', 'ubench', 'divcheck.c'), '-o', exe, '-lm'], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert 'mismatches 0' in out, out
+
+
 def test_official_swin_checkpoint_loads_like_the_reference(golden):
     """§8 f2: ``DepthFormerSwin.load_pretrained`` on an official-layout Swin checkpoint (5x5-window bias tables, 3-channel
     patch embedding) gives the tensors the reference's ``init_weights`` produced from the same file

@@ -522,6 +522,100 @@ def test_msda_raw_fused_prepare_and_sampling(dev, dtype, case):
         close_scaled(fused[3], fc.grad, rel=2e-4, what='d ref vs oracle')
 
 
+# ---- deformable attention as MFMA contractions on LDS windows (csrc/msda_mm.hip, round 4)
+def _mm_refs(qshapes):
+    """Pixel-centre reference points, moved OFF the k/64 grid of bf16 offsets: a sample that lands exactly on a pixel sits on the kink
+    of the bilinear gradient, where the last bit of the location decides which one-sided derivative d_offset gets."""
+    r = []
+    for h, w in qshapes:
+        gy, gx = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        r.append(torch.stack((gx.reshape(-1) + 0.013 / w, gy.reshape(-1) + 0.017 / h), -1))
+    return torch.cat(r, 0)
+
+
+_MM_CASES = {
+    # name: (value shapes, query shapes, offset scale in pixels, reference points, query order)
+    'self-tiles': (((44, 70), (22, 35), (11, 18), (6, 9)), 'same', 2.5, 'grid', 'tile'),
+    'self-identity': (((44, 70), (22, 35), (11, 18), (6, 9)), 'same', 2.5, 'grid', None),
+    'cross-grid': (((22, 35), (11, 18), (6, 9), (3, 5)), ((44, 70),), 2.5, 'grid', 'tile'),
+    'cross-sorted': (((44, 70), (22, 35), (11, 18), (6, 9)), ((37, 41),), 2.5, 'rand', 'ref'),
+    'scattered': (((44, 70), (22, 35), (11, 18), (6, 9)), ((37, 41),), 6.0, 'rand', 'randperm'),      # windows of many chunks
+    'ragged': (((37, 53), (19, 27), (10, 14), (5, 7)), ((21, 45), (3, 5)), 4.0, 'grid', 'tile'),          # Nq % 32 != 0
+    'tiny': (((3, 5), (2, 3), (1, 2), (1, 1)), ((2, 3),), 1.0, 'grid', 'tile'),                          # one partial tile, 1 x 1 level
+}
+
+
+@pytest.mark.parametrize('case', sorted(_MM_CASES))
+def test_msda_mm_fwd_bwd_vs_oracle(dev, case):
+    """kernels.ms_deform_attn_mm (ge_msda_fwd_mm / ge_msda_bwd_lw_mm / ge_msda_bwd_value / ge_msda_dref) against mmcv's arithmetic
+    written out in torch on the CPU with the oracle's sampling core, differentiated by autograd, on the SAME bf16-rounded value /
+    raw / gradient tensors: out, d_value, d_offsets, d_logits, d_reference_points.  Tolerance 1e-2 of each tensor's scale = one bf16
+    rounding of the result (measured 2e-3 ... 6e-3).  The query order never changes the result."""
+    from gedepth_amd import kernels as K
+    shapes, qshapes, jitter, ref_mode, order_mode = _MM_CASES[case]
+    qshapes = shapes if qshapes == 'same' else qshapes
+    B, nH, L, P = 2, 8, 4, 8
+    g = gen(sum(map(ord, case)))
+    nv, nq = sum(h * w for h, w in shapes), sum(h * w for h, w in qshapes)
+    n_off = nH * L * P * 2
+    value = torch.randn(B, nv, nH, 64, generator=g).bfloat16()
+    raw = torch.cat((torch.randn(B, nq, n_off, generator=g) * jitter, torch.randn(B, nq, nH * L * P, generator=g)), -1).bfloat16()
+    ref = _mm_refs(qshapes) if ref_mode == 'grid' else torch.rand(nq, 2, generator=g) * 1.2 - 0.1       # incl. points outside the maps
+    ref = ref[None, :, None, :].expand(B, nq, L, 2).contiguous()
+    go = torch.randn(B, nq, nH * 64, generator=g).bfloat16()
+    vc, rc, fc = value.float().requires_grad_(True), raw.float().requires_grad_(True), ref.clone().requires_grad_(True)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32).view(1, 1, 1, L, 1, 2)
+    loc = fc[:, :, None, :, None, :] + rc[..., :n_off].view(B, nq, nH, L, P, 2) / norm
+    aw = rc[..., n_off:].view(B, nq, nH, L * P).softmax(-1).view(B, nq, nH, L, P)
+    want = O.msda_core(vc, shapes, loc, aw)
+    want.backward(go.float())
+    order = {'tile': lambda: K.msda_tile_order(qshapes, dev), 'ref': lambda: K.msda_ref_order(ref[0, :, 0].to(dev), shapes[0]),
+             'randperm': lambda: torch.randperm(nq, generator=g).to(torch.int32).to(dev), None: lambda: None}[order_mode]()
+    assert K.msda_mm_supported(value.to(dev), raw.to(dev), shapes, nH, L, P)
+    v, r, f = value.to(dev).requires_grad_(True), raw.to(dev).requires_grad_(True), ref.to(dev).requires_grad_(True)
+    out = K.ms_deform_attn_mm(v, r, f, shapes, order, nH, L, P)
+    out.backward(go.to(dev))
+    close_scaled(out.float(), want, rel=1e-2, what='out')
+    close_scaled(v.grad.float(), vc.grad, rel=1e-2, what='d value')
+    close_scaled(r.grad[..., :n_off].float(), rc.grad[..., :n_off], rel=1e-2, what='d offsets')
+    close_scaled(r.grad[..., n_off:].float(), rc.grad[..., n_off:], rel=1e-2, what='d logits')
+    close_scaled(f.grad, fc.grad, rel=1e-2, what='d reference points')
+    # the same call in another order: identical up to the bf16 rounding of the coefficient sums (different tiles, different chunking)
+    other = torch.arange(nq - 1, -1, -1, dtype=torch.int32, device=dev)
+    out2 = K.ms_deform_attn_mm(v.detach(), r.detach(), f.detach(), shapes, other, nH, L, P)
+    close_scaled(out2.float(), out.float(), rel=1e-2, what='reversed query order')
+
+
+def test_msda_mm_matches_gather_kernels_on_exact_pixel_samples(dev):
+    """At initialisation the self-attention samples EXACT pixel positions (pixel-centre reference points + integer offsets), i.e.
+    every sample sits on the kink of the bilinear gradient.  The MFMA path computes the locations in mmcv's arithmetic to the bit
+    (tools/ubench/msda_mm/divcheck.c: its reciprocal + FMA division is IEEE division for every bf16 offset), so it takes the same one-sided
+    derivatives as the gather kernels (ge_msda_fwd_raw / ge_msda_bwd_raw), whose kink decisions the fp32 parity tests pin."""
+    from gedepth_amd import kernels as K
+    from gedepth_amd.mmrt.bricks import msda_offset_bias
+    shapes = [(22, 35), (11, 18), (6, 9), (3, 5)]
+    B, nH, L, P = 2, 8, 4, 8
+    nq = sum(h * w for h, w in shapes)
+    g = gen(29)
+    value = torch.randn(B, nq, nH, 64, generator=g).bfloat16().to(dev)
+    raw = torch.cat((msda_offset_bias(nH, L, P)[None, None].expand(B, nq, -1), 0.3 * torch.randn(B, nq, nH * L * P, generator=g)), -1).bfloat16().to(dev)
+    refs = []
+    for h, w in shapes:
+        gy, gx = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing='ij')
+        refs.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(B, nq, L, 2).contiguous().to(dev)
+    go = torch.randn(B, nq, nH * 64, generator=g).bfloat16().to(dev)
+    res = []
+    for fn in (lambda v, r: K.ms_deform_attn_mm(v, r, ref, shapes, K.msda_tile_order(shapes, dev), nH, L, P),
+               lambda v, r: K.ms_deform_attn_raw(v, r, ref, shapes, shapes, nH, L, P)):
+        v, r = value.clone().requires_grad_(True), raw.clone().requires_grad_(True)
+        out = fn(v, r)
+        out.backward(go)
+        res.append([t.float().cpu() for t in (out, v.grad, r.grad)])
+    for a, b, n in zip(res[0], res[1], ('out', 'd value', 'd raw')):
+        close_scaled(a, b, rel=1e-2, what=f'MFMA path vs gather kernels on exact-pixel samples: {n}')
+
+
 def test_msda_module_golden(dev, golden):
     """Whole MultiScaleDeformableAttention module vs the fixture (mmcv 1.3.13 semantics, dropout off)."""
     from gedepth_amd.depth.models.necks.hahi import MultiScaleDeformableAttention
