@@ -109,8 +109,9 @@ struct MsdaWs {            // device workspace carved by the host wrapper
 };
 
 // bf16 drain of the binned d_value on the matrix cores (msda_drain_mfma.hip); tr = use ds_read_b64_tr_b16 for the B operand
+// rec8 = 8-byte records {query << 7 | corner, bf16 weight | 8-bit frac x << 16 | 8-bit frac y << 24} (msda_hist_raw_k)
 int msda_drain_mfma_launch(const MsdaLevels& lv, const MsdaBins& bins, const MsdaWs& ws, const void* gout, float* d_value, int nbins,
-                           int Nv, int Nq, int nH, int L, bool tr, hipStream_t s);
+                           int Nv, int Nq, int nH, int L, bool tr, hipStream_t s, bool rec8 = false);
 
 
 // LDS-window kernels (msda_win.hip); query geometry = n_qseg (H, W) segments of queries in raster order

@@ -548,6 +548,103 @@ __global__ void __launch_bounds__(1024) msda_hist_k(MsdaLevels lv, MsdaBins bins
   }
 }
 
+// The same two passes fed from the RAW projection outputs (bf16) + reference points instead of the fp32 loc / attw tensors (round 4:
+// those 2.4 GB per cross-attention launch are no longer written by the forward, ge_msda_fwd_mm), L == 4, P == 8: thread = sampling
+// point, the 32 points of a (query, head) are one half wave — locations in the forward's arithmetic to the bit (mm_div: the tile and
+// the cell of every tap must be the forward's), the softmax over the half wave on the DPP network (FILL only), 8-byte records.
+struct MsdaRawIn {
+  const bf16_t* off; long off_ld; const bf16_t* logit; long logit_ld;
+  const float* ref; long ref_sb, ref_sq, ref_sl;
+  float fW[4], fH[4], rW[4], rH[4];                     // map sizes and their correctly rounded reciprocals
+};
+__device__ __forceinline__ float msda_div(float n, float d, float r) {       // = n / d for bf16-valued n, integer d <= 8191 (msda_mm.hip)
+  const float q0 = n * r;
+  return __builtin_fmaf(__builtin_fmaf(-q0, d, n), r, q0);
+}
+__device__ __forceinline__ float msda_half_max(float v) {                    // over the 32 lanes of a half wave, result in every lane
+#define MSDA_DPP_F(V, CTRL, RM) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(V), __float_as_int(V), CTRL, RM, 0xf, false))
+  v = fmaxf(v, MSDA_DPP_F(v, 0x111, 0xf)); v = fmaxf(v, MSDA_DPP_F(v, 0x112, 0xf));
+  v = fmaxf(v, MSDA_DPP_F(v, 0x114, 0xf)); v = fmaxf(v, MSDA_DPP_F(v, 0x118, 0xf));
+  v = fmaxf(v, MSDA_DPP_F(v, 0x142, 0xa));
+#undef MSDA_DPP_F
+  const float a = readlane_f(v, 31), b = readlane_f(v, 63);
+  return (threadIdx.x & 32) ? b : a;
+}
+__device__ __forceinline__ float msda_half_sum(float v) {
+#define MSDA_DPP_Z(V, CTRL, RM) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, RM, 0xf, true))
+  v += MSDA_DPP_Z(v, 0x111, 0xf); v += MSDA_DPP_Z(v, 0x112, 0xf);            // inclusive scan inside the 16-lane rows
+  v += MSDA_DPP_Z(v, 0x114, 0xf); v += MSDA_DPP_Z(v, 0x118, 0xf);
+  v += MSDA_DPP_Z(v, 0x142, 0xa);                                            // row totals of rows 0 / 2 into rows 1 / 3
+#undef MSDA_DPP_Z
+  const float a = readlane_f(v, 31), b = readlane_f(v, 63);
+  return (threadIdx.x & 32) ? b : a;
+}
+template <bool FILL>
+__global__ void __launch_bounds__(1024) msda_hist_raw_k(MsdaLevels lv, MsdaBins bins, MsdaRawIn in, MsdaWs ws, int Nq, int nH, int R, int B) {
+  extern __shared__ int hist[];
+  const int ntiles = bins.first_tile[4];
+  const int nunits = B * nH * R;
+  for (int u = blockIdx.x; u < nunits; u += gridDim.x) {          // u = (b * nH + head) * R + r
+    const int r = u % R, bh = u / R;
+    const int head = bh % nH, b = bh / nH;
+    int* gh = ws.seg_hist + (long)u * ntiles;
+    for (int i = threadIdx.x; i < ntiles; i += 1024) hist[i] = FILL ? gh[i] : 0;
+    __syncthreads();
+    const int q_lo = (int)((long)Nq * r / R), q_hi = (int)((long)Nq * (r + 1) / R);
+    const int n = (q_hi - q_lo) * 32;
+    for (int j0 = 0; j0 < n; j0 += 1024) {                        // uniform trip count per wave: the softmax needs whole half waves
+      const int j = j0 + threadIdx.x;
+      const bool live = j < n;
+      const int qi = live ? j >> 5 : 0, lp = j & 31, l = lp >> 3;
+      const int q = q_lo + qi;
+      const long row = (long)b * Nq + q;
+      const uint32_t o = *(const uint32_t*)(in.off + row * in.off_ld + head * 64 + lp * 2);
+      const float* rp = in.ref + (long)b * in.ref_sb + (long)q * in.ref_sq + (long)l * in.ref_sl;
+      const float fW = in.fW[l], fH = in.fH[l];
+      const float lx = rp[0] + msda_div(__uint_as_float(o << 16), fW, in.rW[l]);
+      const float ly = rp[1] + msda_div(__uint_as_float(o & 0xffff0000u), fH, in.rH[l]);
+      const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+      float wgt = 0.f;
+      if (FILL) {
+        const float lg = bf2f(in.logit[row * in.logit_ld + head * 32 + lp]);
+        const float e = __expf(lg - msda_half_max(lg));
+        wgt = e * (1.f / msda_half_sum(e));
+      }
+      if (!(live && y > -1.f && x > -1.f && y < fH && x < fW)) continue;
+      const int Hl = lv.H[l], Wl = lv.W[l];
+      const float xf = floorf(x), yf = floorf(y);
+      const int x0 = (int)xf, y0 = (int)yf;
+      const float ax = x - xf, ay = y - yf;
+      const int ntx = bins.ntx[l];
+      const int lb0 = bins.first_tile[l];
+      const bool xa = x0 >= 0, xb = x0 + 1 < Wl, ya = y0 >= 0, yb = y0 + 1 < Hl;
+      const int txa = x0 >> 3, txb = (x0 + 1) >> 3, tya = y0 >> 2, tyb = (y0 + 1) >> 2;
+      const int tx_first = xa ? txa : txb, ty_first = ya ? tya : tyb;
+      const int two_x = (xa && xb && txb != txa) ? 1 : 0, two_y = (ya && yb && tyb != tya) ? 1 : 0;
+      // bf16 weight, fractions at 8 bits (floor: the drain reads them back at the centre of the step)
+      const uint32_t packed = (uint32_t)f2bf(wgt) | ((uint32_t)min((int)(ax * 256.f), 255) << 16) | ((uint32_t)min((int)(ay * 256.f), 255) << 24);
+      for (int jy = 0; jy <= two_y; ++jy)
+        for (int jx = 0; jx <= two_x; ++jx) {
+          const int tx = jx ? txb : tx_first, ty = jy ? tyb : ty_first;
+          const int slot = atomicAdd(&hist[lb0 + mul24(ty, ntx) + tx], 1);        // LDS
+          if (FILL) {
+            const int lx1 = x0 - tx * MSDA_TW + 1, ly1 = y0 - ty * MSDA_TH + 1;
+            ((int2*)ws.entries)[slot] = make_int2((q << 7) | (ly1 << 4) | lx1, (int)packed);
+          }
+        }
+    }
+    __syncthreads();
+    if (!FILL) {
+      for (int i = threadIdx.x; i < ntiles; i += 1024) {
+        const int c = hist[i];
+        gh[i] = c;
+        if (c) atomicAdd(&ws.cnt[bh * ntiles + i], c);
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // seg_hist[unit = bh * R + r][tile] (counts) -> absolute first slot of unit r in bin bh * ntiles + tile
 __global__ void __launch_bounds__(256) msda_segscan_k(MsdaWs ws, int ntiles, int R, int nbins) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1082,6 +1179,64 @@ extern "C" int ge_msda_bwd_value(const void* value, const int* spatial_hw, const
                                  int dtype, void* stream) {
   return msda_bwd_impl(value, spatial_hw, nullptr, 0, loc, attw, d_out, d_value, nullptr, nullptr, workspace, workspace_bytes, B, Nv, Nq,
                        nH, L, P, dtype, stream, nullptr, true);
+}
+
+// d_value from the raw projections (bf16 storage, L == 4, P == 8): count / scan / fill with 8-byte records, MFMA drain.  Same workspace
+// as ge_msda_bwd (ge_msda_bwd_workspace); d_value f32, zero-filled by the caller.
+extern "C" int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                                     const float* ref, long ref_sb, long ref_sq, long ref_sl, const void* d_out, float* d_value,
+                                     void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype,
+                                     void* stream) {
+  if (!spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_value || !workspace || B < 0 || Nq < 0 || nH <= 0) return GE_ERR_BAD_ARG;
+  if (dtype != GE_BF16 || L != 4 || P != 8) return GE_ERR_UNSUPPORTED;
+  MsdaLevels lv;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  for (int l = 0; l < L; ++l) if (lv.W[l] > 8191 || lv.H[l] > 8191) return GE_ERR_UNSUPPORTED;
+  if ((long)B * Nq * nH == 0) return GE_OK;
+  MsdaBins bins;
+  msda_bins(lv, L, bins);
+  const MsdaPlan pl = msda_plan(bins, B, Nq, nH, L, P);
+  const long seg_ints = (long)B * nH * pl.R * pl.ntiles;
+  if (!pl.ok || workspace_bytes < msda_ws_layout(pl.nbins, seg_ints, pl.max_entries, nullptr, nullptr)) return GE_ERR_UNSUPPORTED;
+  hipStream_t s = ge_stream(stream);
+  MsdaRawIn in;
+  in.off = (const bf16_t*)off_raw; in.off_ld = off_ld; in.logit = (const bf16_t*)logit_raw; in.logit_ld = logit_ld;
+  in.ref = ref; in.ref_sb = ref_sb; in.ref_sq = ref_sq; in.ref_sl = ref_sl;
+  for (int l = 0; l < 4; ++l) { in.fW[l] = (float)lv.W[l]; in.fH[l] = (float)lv.H[l]; in.rW[l] = 1.f / in.fW[l]; in.rH[l] = 1.f / in.fH[l]; }
+  hipEvent_t evs[MSDA_NSTAGE + 1];
+  hipEvent_t* ev = nullptr;
+  { std::lock_guard<std::mutex> lk(g_msda_mu); if (g_msda_timing) ev = evs; }
+  msda_mark(ev, 0, s);
+  msda_mark(ev, 1, s);
+  const int nbins = pl.nbins;
+  MsdaWs ws;
+  msda_ws_layout(nbins, seg_ints, pl.max_entries, (char*)workspace, &ws);
+  hipError_t he = hipMemsetAsync(ws.cnt, 0, (size_t)nbins * 4, s);
+  if (he != hipSuccess) return (int)he;
+  const unsigned hgrid = (unsigned)std::min((long)MSDA_HIST_WGS, (long)B * nH * pl.R);
+  const size_t hsmem = (size_t)pl.ntiles * 4;
+  msda_hist_raw_k<false><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B);
+  GE_LAUNCH_CHECK();
+  msda_mark(ev, 2, s);
+  msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
+  GE_LAUNCH_CHECK();
+  msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.ntiles, pl.R, nbins);
+  GE_LAUNCH_CHECK();
+  msda_mark(ev, 3, s);
+  msda_hist_raw_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B);
+  GE_LAUNCH_CHECK();
+  msda_mark(ev, 4, s);
+  g_msda_drain_mfma_used = true;
+  g_msda_lw_win_used = false;
+  e = msda_drain_mfma_launch(lv, bins, ws, d_out, d_value, nbins, Nv, Nq, nH, L, true, s, true);
+  if (e) return e;
+  msda_mark(ev, 5, s);
+  if (ev) {
+    std::lock_guard<std::mutex> lk(g_msda_mu);
+    for (int i = 0; i < MSDA_NSTAGE; ++i) g_msda_pending.push_back(MsdaStageRec{i, ev[i], ev[i + 1]});
+  }
+  return GE_OK;
 }
 
 // ============================================================================ sampling-location / weight preparation

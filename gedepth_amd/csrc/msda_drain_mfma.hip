@@ -31,7 +31,27 @@ typedef float md_f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 __device__ __forceinline__ bf16_t md_bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }   // v_cvt_pk_bf16_f32, RNE
 
-template <bool TR>
+// REC8: 8-byte records (bf16 weight, 8-bit fractions: the coefficients are rounded to bf16 in the image anyway; a fraction is taken at
+// the centre of its 1/256 step, so a coefficient moves by <= 2^-9 of the point's weight) — half the record bytes of fill and drain.
+template <bool REC8> struct MdRec;
+template <> struct MdRec<false> {
+  typedef int4 T;
+  static __device__ __forceinline__ T pad(int key) { return make_int4(key, 0, 0, 0); }
+  static __device__ __forceinline__ int key(const T& e) { return e.x; }
+  static __device__ __forceinline__ void coef(const T& e, float& w, float& ax, float& ay) { w = __int_as_float(e.y); ax = __int_as_float(e.z); ay = __int_as_float(e.w); }
+};
+template <> struct MdRec<true> {
+  typedef int2 T;
+  static __device__ __forceinline__ T pad(int key) { return make_int2(key, 0); }
+  static __device__ __forceinline__ int key(const T& e) { return e.x; }
+  static __device__ __forceinline__ void coef(const T& e, float& w, float& ax, float& ay) {
+    w = __uint_as_float((uint32_t)e.y << 16);
+    ax = ((float)(((uint32_t)e.y >> 16) & 255u) + 0.5f) * (1.f / 256.f);
+    ay = ((float)((uint32_t)e.y >> 24) + 0.5f) * (1.f / 256.f);
+  }
+};
+
+template <bool TR, bool REC8>
 __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins bins, MsdaWs ws, const bf16_t* __restrict__ gout,
                                                          float* __restrict__ d_value, int nbins, int Nv, int Nq, int nH, int L) {
   __shared__ __attribute__((aligned(16))) bf16_t stage_all[4 * MD_STAGE];
@@ -75,7 +95,8 @@ __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins
     const int chunk = item - ws.chunk_first[bin];
     const int cnt = ws.cnt[bin];
     const int e_lo = chunk * MSDA_CHUNK, e_hi = min(cnt, e_lo + MSDA_CHUNK);
-    const int4* ent = ws.entries + ws.offset[bin] + e_lo;
+    typedef typename MdRec<REC8>::T rec_t;
+    const rec_t* ent = (const rec_t*)ws.entries + ws.offset[bin] + e_lo;
     const int n = e_hi - e_lo;
     const int bh = bin / ntiles, tile = bin - bh * ntiles;
     const int b = bh / nH, head = bh - b * nH;
@@ -89,14 +110,13 @@ __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins
     md_f32x16 acc0 = 0.f, acc1 = 0.f;
     const int nb = (n + MD_BLK - 1) / MD_BLK;
     u32x4_t R[8];
-    int4 E0, E1, E2;
+    rec_t E0, E1, E2;
     // a record slot past the end of the chunk: zero weight, the query of the chunk's first record (a row that exists)
-    const int4 first = ent[0];
-    const int4 padrec = make_int4(first.x, 0, 0, 0);
+    const rec_t padrec = MdRec<REC8>::pad(MdRec<REC8>::key(ent[0]));
 #define MD_LOAD(DST, BLK) { DST = padrec; if ((BLK) * MD_BLK + lane < n) DST = ent[(BLK) * MD_BLK + lane]; }
 #define MD_GATHER(EE)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
-    const int q = __shfl((EE).x >> 7, i * 8 + row8, 64);                                       \
+    const int q = __shfl(MdRec<REC8>::key(EE) >> 7, i * 8 + row8, 64);                                       \
     R[i] = *(const u32x4_t*)(grow + (long)q * qpitch);                                         \
   }
 #define MD_PARK()                                                                              \
@@ -104,8 +124,9 @@ __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins
     // the four coefficients of this lane's record -> the A image (ZERO = true: clear the same slots again)
 #define MD_COEF(EE, ZERO)                                                                      \
   {                                                                                            \
-    const int lx = ((EE).x & 15) - 1, ly = (((EE).x >> 4) & 7) - 1;                             \
-    const float w = __int_as_float((EE).y), ax = __int_as_float((EE).z), ay = __int_as_float((EE).w); \
+    const int lx = (MdRec<REC8>::key(EE) & 15) - 1, ly = ((MdRec<REC8>::key(EE) >> 4) & 7) - 1; \
+    float w, ax, ay;                                                                            \
+    MdRec<REC8>::coef(EE, w, ax, ay);                                                           \
     const bool xl = lx >= 0, xr = lx < MSDA_TW - 1, yt = ly >= 0, yb = ly < MSDA_TH - 1;        \
     const float wl = 1.f - ax, wt = w * (1.f - ay), wb = w * ay;                                \
     bf16_t* a00 = aimg + a_rec + (ly * MSDA_TW + lx) * 8;                                       \
@@ -178,9 +199,10 @@ __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins
 }
 
 int msda_drain_mfma_launch(const MsdaLevels& lv, const MsdaBins& bins, const MsdaWs& ws, const void* gout, float* d_value, int nbins,
-                           int Nv, int Nq, int nH, int L, bool tr, hipStream_t s) {
-  if (tr) msda_drain_mfma_k<true><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)gout, d_value, nbins, Nv, Nq, nH, L);
-  else msda_drain_mfma_k<false><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)gout, d_value, nbins, Nv, Nq, nH, L);
+                           int Nv, int Nq, int nH, int L, bool tr, hipStream_t s, bool rec8) {
+  if (rec8) msda_drain_mfma_k<true, true><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)gout, d_value, nbins, Nv, Nq, nH, L);
+  else if (tr) msda_drain_mfma_k<true, false><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)gout, d_value, nbins, Nv, Nq, nH, L);
+  else msda_drain_mfma_k<false, false><<<256 * 3, 256, 0, s>>>(lv, bins, ws, (const bf16_t*)gout, d_value, nbins, Nv, Nq, nH, L);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -437,14 +437,14 @@ class _MSDeformAttnMM(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, raw, ref, order, spatial_shapes, nH, L, P):
-        out, loc, attw = msda_fwd_mm(value, raw, ref, spatial_shapes, order, want_loc=True, nH=nH, L=L, P=P)
-        ctx.save_for_backward(value, raw, ref, order, loc, attw)
+        out = msda_fwd_mm(value, raw, ref, spatial_shapes, order, want_loc=False, nH=nH, L=L, P=P)    # no fp32 loc / attw tensors exist
+        ctx.save_for_backward(value, raw, ref, order)
         ctx.meta = (tuple(tuple(int(v) for v in hw) for hw in spatial_shapes), nH, L, P)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        value, raw, ref, order, loc, attw = ctx.saved_tensors
+        value, raw, ref, order = ctx.saved_tensors
         shapes, nH, L, P = ctx.meta
         value, raw = _c(value), _c(raw)
         B, Nv, _, D = value.shape
@@ -474,13 +474,13 @@ class _MSDeformAttnMM(torch.autograd.Function):
             ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
             assert ws_bytes > 0, 'binned d_value path unavailable for this geometry'
             ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8)
-            if PROFILER.on:
-                la_b = (loc.numel() + attw.numel()) * 4
-                PROFILER.add_stage_bytes((0, la_b, 0, la_b, d_out.numel() * 2 + d_value.numel() * 4))
-            PROFILER.run(f'msda_bwd_value[B{B} Nq{Nq} Nv{Nv}]', 2 * (loc.numel() + attw.numel()) * 4 + d_out.numel() * 2 + d_value.numel() * 4,
-                         lambda: hip.check(lib.ge_msda_bwd_value(hip.ptr(value), shapes_p, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out),
-                                                                 hip.ptr(d_value), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P,
-                                                                 hip.dtype_code(value), hip.stream()), 'ge_msda_bwd_value'))
+            if PROFILER.on:       # algorithmic bytes per stage: count reads the offsets, fill offsets + logits, drain d_out + d_value
+                PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, d_out.numel() * 2 + d_value.numel() * 4))
+            PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}]', B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
+                         lambda: hip.check(lib.ge_msda_bwd_value_raw(
+                             shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+                             hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value),
+                             hip.stream()), 'ge_msda_bwd_value_raw'))
             d_value = d_value.to(value.dtype)
         return d_value, d_raw, d_ref, None, None, None, None, None
 

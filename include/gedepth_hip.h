@@ -186,6 +186,11 @@ int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_
                       void* stream);
 int ge_msda_bwd_value(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out, float* d_value,
                       void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+/* ge_msda_bwd_value fed from the raw projections instead of loc / attw (bf16, L == 4, P == 8; 8-byte records): with it the forward
+ * needs no loc / attw output at all. */
+int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
+                          long ref_sb, long ref_sq, long ref_sl, const void* d_out, float* d_value, void* workspace,
+                          size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 int ge_msda_dref(const void* d_off_raw, long off_ld, const int* spatial_hw, float* d_ref, long rows, int nH, int L, int P, int dtype,
                  void* stream);
 int ge_tokens_from_map(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
