@@ -383,6 +383,22 @@ def main():
             model.eval()
             with torch.no_grad():
                 depth_eval = model.encode_decode(img, metas)
+            if arch == 'T':
+                # the test path through the reference's OWN methods (encoder_decoder.py:196-274): simple_test on the plain view and
+                # aug_test over (view, horizontally flipped view) with the flip-back inside `inference`; a second pair of views comes
+                # at another size so that the rescale inside encode_decode is exercised through aug_test as well
+                metas_f = [dict(metas[0], flip=True, flip_direction='horizontal')] * 2
+                metas_n = [dict(metas[0], flip_direction='horizontal')] * 2
+                zero_pt = [torch.zeros(2, 2), torch.zeros(2, 2)]
+                with torch.no_grad():
+                    kw_t = dict(pe_ori_point=zero_pt)
+                    if adaptive:
+                        kw_t['pe_k_gt'] = [pe_k_gt, pe_k_gt.flip(-1)]
+                    simple = np.stack(model.simple_test(img, metas_n, rescale=True, **kw_t))
+                    aug = np.stack(model.aug_test([img, img.flip(3)], [metas_n, metas_f], rescale=True, **kw_t))
+                    vflip = [dict(metas[0], flip=True, flip_direction='vertical')] * 2
+                    aug_v = np.stack(model.aug_test([img, img.flip(2)], [metas_n, vflip], rescale=True, **kw_t))
+                save(f'test_path_{arch}_{"A" if adaptive else "V"}', img=img, simple=simple, aug_h=aug, aug_v=aug_v)
             model.train()
             state_before = {k: v.clone() for k, v in model.state_dict().items()}
             kw = dict(pe_k_gt=pe_k_gt) if adaptive else {}

@@ -96,6 +96,30 @@ def _capture_kink_decisions(model):
             h.remove()
 
 
+@pytest.mark.parametrize('cfg_name,tag,adaptive', [('depthformer_swint_v.py', 'T_V', False), ('depthformer_swint_a.py', 'T_A', True)])
+def test_test_path_vs_reference_fixture(dev, golden, cfg_name, tag, adaptive):
+    """The product's test path (``forward(return_loss=False)`` -> ``simple_test`` / ``aug_test`` -> ``inference`` with the flip-back,
+    depther/encoder_decoder.py) on the HIP kernels against arrays the reference's OWN ``simple_test`` / ``aug_test`` wrote
+    (tests/golden/make_golden.py -> test_path_*.npz): fp32, exact-fp32 window attention, 1e-4 relative like the eval depth."""
+    g = golden(f'test_path_{tag}')
+    model = build(cfg_name)
+    load_filled(model, 'e2e')
+    model = model.to(dev).eval()
+    set_exact(model)
+    img = T(g['img']).to(dev)
+    meta = dict(ori_shape=(64, 96, 3), flip=False, flip_direction='horizontal')
+    zero = [torch.zeros(2, 2, device=dev)] * 2
+    rel = lambda a, b: (np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max()
+    with torch.no_grad():
+        simple = np.stack(model([img], [[meta] * 2], return_loss=False, pe_ori_point=zero[:1]))
+        assert rel(simple, g['simple']) <= 1e-4, rel(simple, g['simple'])
+        for direction, dim, key in (('horizontal', 3, 'aug_h'), ('vertical', 2, 'aug_v')):
+            flipped = dict(meta, flip=True, flip_direction=direction)
+            aug = np.stack(model([img, img.flip(dim)], [[meta] * 2, [flipped] * 2], return_loss=False, pe_ori_point=zero))
+            assert aug.shape == g[key].shape
+            assert rel(aug, g[key]) <= 1e-4, (direction, rel(aug, g[key]))
+
+
 @pytest.mark.parametrize('cfg_name,tag,adaptive', [('depthformer_swint_v.py', 'e2e_T_V', False),
                                                    ('depthformer_swint_a.py', 'e2e_T_A', True),
                                                    ('depthformer_a.py', 'e2e_L_A', True)])

@@ -245,6 +245,27 @@ def test_e2e(golden, tag, arch, adaptive):
     assert abs(total.item() - float(g['grad_norm_total'])) <= 1e-3 * float(g['grad_norm_total'])
 
 
+@pytest.mark.parametrize('tag,adaptive', [('T_V', False), ('T_A', True)])
+def test_test_path_vs_reference_methods(golden, tag, adaptive):
+    """The oracle's restatement of the test path (``inference`` / ``aug_test``, encoder_decoder.py:196-274) against arrays written
+    by the reference's OWN ``simple_test`` and ``aug_test`` (tests/golden/make_golden.py: plain view, horizontal- and vertical-flip
+    pairs, flip-back inside ``inference``) on the e2e toy model — the last oracle function that had no reference-generated pin."""
+    g, ge = golden(f'test_path_{tag}'), golden(f'e2e_{tag}')
+    P = weights(ge, 'e2e')
+    cfg = dict(O.SWIN_T, adaptive=adaptive)
+    img = T(g['img'])
+    meta = dict(ori_shape=(64, 96, 3), flip=False, flip_direction='horizontal')
+    with torch.no_grad():
+        simple = O.inference(img, [meta] * 2, P, cfg)
+        close(simple, g['simple'], rtol=3e-4, atol=1e-4)
+        for direction, dim, key in (('horizontal', 3, 'aug_h'), ('vertical', 2, 'aug_v')):
+            flipped = dict(meta, flip=True, flip_direction=direction)
+            aug = O.aug_test([img, img.flip(dim)], [[meta] * 2, [flipped] * 2], P, cfg)
+            close(aug, g[key], rtol=3e-4, atol=1e-4)
+    # the flip augmentation is not a no-op on this model: the two views disagree by far more than the tolerance
+    assert np.abs(g['aug_h'] - g['simple']).max() > 1e-2
+
+
 @pytest.mark.parametrize('tag', ['e2e_T_V', 'e2e_L_A'])
 def test_reference_fixture_vs_float64_oracle(golden, tag):
     """How far the REFERENCE's own fp32 (CPU) results are from the same algorithm in float64 (tests/f64ref.py): the
