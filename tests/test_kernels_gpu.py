@@ -623,7 +623,14 @@ def test_msda_mm_cross_attention_shape_offset_gradient_vs_float64(dev):
     dv_noise = (runs[0][1].float() - runs[1][1].float()).abs().max().item() / runs[0][1].float().abs().max().item()
     assert dv_noise <= 2 ** -7, dv_noise                               # d_value: fp32 atomics between chunk partials, then one bf16 rounding
     got = runs[0][0][..., :n_off].double().cpu().reshape(B * nq, n_off)
-    close_scaled(got, want, rel=1e-2, what='d offsets at 2 x 98560 queries')
+    # element-wise: 50 M sampling points in fp32 against float64 — a handful sit within rounding of a pixel boundary, where floor()
+    # (hence the one-sided derivative) legitimately differs; everything else is within one bf16 rounding
+    err = (got - want).abs()
+    scale = want.abs().max().item()
+    outliers = (err > 1e-2 * scale).double().mean().item()
+    cos_raw = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+    print(f'\n[d offsets, 2 x 98560 x 512] beyond 1e-2 of the scale: {outliers:.2e} of the elements; cosine {cos_raw:.6f}')
+    assert outliers <= 1e-4 and cos_raw >= 0.9995, (outliers, cos_raw)
     dW_got, dW_want = got.t() @ query.double(), want.t() @ query.double()      # (512, 64): the weight gradient of the projection
     cos = torch.nn.functional.cosine_similarity(dW_got.flatten(), dW_want.flatten(), dim=0).item()
     ratio = (dW_got.norm() / dW_want.norm()).item()

@@ -327,6 +327,129 @@ def test_config2_bf16_full_shape_step_vs_fp32(dev):
     assert all(torch.isfinite(p).all() for p in model.parameters())
 
 
+def _learnable_batch(B, H, W, seed, dev, valid_fraction=0.3):
+    """synthetic_batch with a target the network can actually learn from its input: the flat-ground depth of channel 4, modulated by
+    the red channel (the stock synthetic target is noise — fine for throughput, useless for a convergence comparison)."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    b = synthetic_batch(B, H, W, seed=seed, device=dev, valid_fraction=valid_fraction)
+    ground = b['img'][:, 4:5].abs().clamp(1.0, 70.0)
+    target = (ground * (1.0 + 0.25 * torch.tanh(b['img'][:, 0:1]))).clamp(1.0, 80.0)
+    b['depth_gt'] = torch.where(b['depth_gt'] > 0, target, torch.zeros_like(target))
+    return b
+
+
+def test_bf16_eval_error_budget_per_module(dev):
+    """Round-3 review, weak #2: bf16 eval depth sits ~2 % (mean relative) from fp32 at the bench shape on random-init weights, and
+    nothing said where that comes from.  The model is evaluated at 1 x 352 x 1120 with ONE top-level module at a time under bf16
+    autocast (its inputs and outputs cast at the boundary, everything else fp32): the per-module contributions are recorded in
+    gpurun_out/parity_e2e.json and bounded, and the all-bf16 error is checked to be explained by them (no super-additive blow-up)."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    model = build('depthformer_swint_v.py')
+    model.init_weights()
+    model = model.to(dev).eval()
+    batch = synthetic_batch(1, 352, 1120, seed=7, device=dev)
+    parts = dict(backbone=model.backbone, neck=model.neck, pe_mask_neck=model.pe_mask_neck, decode_head=model.decode_head)
+
+    def cast(o, dt):
+        if torch.is_tensor(o):
+            return o.to(dt) if o.is_floating_point() else o
+        if isinstance(o, (list, tuple)):
+            return type(o)(cast(v, dt) for v in o)
+        return o
+
+    def run(low):
+        saved = {}
+        for name, mod in parts.items():
+            saved[name] = mod.forward
+
+            def fwd(*a, _f=mod.forward, _lp=name in low, **k):
+                if not _lp:
+                    with torch.autocast('cuda', enabled=False):
+                        return _f(*cast(a, torch.float32), **{kk: cast(v, torch.float32) for kk, v in k.items()})
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    return cast(_f(*a, **k), torch.float32)
+            mod.forward = fwd
+        try:
+            with torch.no_grad():
+                return model.encode_decode(batch['img'], batch['img_metas']).float()
+        finally:
+            for name, mod in parts.items():
+                mod.forward = saved[name]
+    ref = run(())
+    rel = lambda d: ((d - ref).abs() / ref.abs().clamp_min(1e-3))
+    rec = {}
+    for name in parts:
+        r = rel(run((name,)))
+        rec[name] = dict(mean_rel=r.mean().item(), max_rel=r.max().item())
+    r = rel(run(tuple(parts)))
+    rec['all'] = dict(mean_rel=r.mean().item(), max_rel=r.max().item())
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        r = rel(model.encode_decode(batch['img'], batch['img_metas']).float())
+    rec['autocast_whole_model'] = dict(mean_rel=r.mean().item(), max_rel=r.max().item())
+    print('\n[bf16 eval error budget, 1x352x1120, random init] ' + '  '.join(f'{k}: mean {v["mean_rel"]:.2e} max {v["max_rel"]:.2e}' for k, v in rec.items()))
+    _log_parity('bf16_eval_error_budget', rec)
+    # bounds = measured x 2 (round 4: backbone 2.7e-3, neck 1.2e-2, PE neck 2.3e-3, head 1.3e-2, all 2.4e-2): the two deformable-attention
+    # blocks of the neck and the eight convolutions of the head carry the error, not the 24 backbone layers
+    budget = dict(backbone=6e-3, neck=2.5e-2, pe_mask_neck=5e-3, decode_head=2.7e-2)
+    for name, b in budget.items():
+        assert rec[name]['mean_rel'] <= b, (name, rec[name])
+    parts_sum = sum(rec[n]['mean_rel'] for n in parts)
+    assert rec['all']['mean_rel'] <= 1.5 * parts_sum + 1e-3, (rec['all'], parts_sum)
+    assert rec['autocast_whole_model']['mean_rel'] <= 1.5 * parts_sum + 1e-3, rec
+
+
+def test_bf16_convergence_parity_with_fp32(dev):
+    """Round-3 review, missing #6: the bf16 performance mode (autocast + fused AdamW with bf16 shadow weights, MFMA attention /
+    convolutions / deformable attention) must TRAIN like the fp32 path.  150 seeded steps from the same initialisation on a learnable
+    synthetic task (2 x 176 x 560, four alternating batches), once in fp32 and once in bf16: the loss curves are compared at the end
+    (mean of the last 20 steps) and both models are scored on a held-out batch with the reference's Abs Rel (fp32 eval of either)."""
+    import copy
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    torch.manual_seed(0)
+    base = build('depthformer_swint_v.py')
+    base.init_weights()
+    init = copy.deepcopy(base.state_dict())
+    batches = [_learnable_batch(2, 176, 560, 100 + i, dev) for i in range(4)]
+    held = _learnable_batch(2, 176, 560, 999, dev)
+    steps = 150
+
+    def train(bf16):
+        torch.manual_seed(1)
+        model = build('depthformer_swint_v.py')
+        model.load_state_dict(init)
+        model = model.to(dev).train()
+        opt_cfg = dict(cfg.optimizer)
+        opt_cfg['lr'] = 1e-4
+        opt = build_optimizer(model, opt_cfg, cfg.optimizer_config.get('grad_clip'))
+        curve = []
+        for it in range(steps):
+            opt.zero_grad()
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bf16):
+                out = model.train_step(batches[it % 4], opt)
+            out['loss'].backward()
+            opt.step()
+            curve.append(float(out['log_vars']['loss']))
+        model.eval()
+        with torch.no_grad():
+            pred = model.encode_decode(held['img'], held['img_metas']).float()
+        gt = held['depth_gt']
+        m = gt > 0
+        absrel = ((pred[m] - gt[m]).abs() / gt[m]).mean().item()
+        return curve, absrel
+    c32, a32 = train(False)
+    c16, a16 = train(True)
+    end32, end16 = float(np.mean(c32[-20:])), float(np.mean(c16[-20:]))
+    print(f'\n[convergence, {steps} steps] loss start {c32[0]:.4f}; end fp32 {end32:.4f} bf16 {end16:.4f}; held-out Abs Rel fp32 {a32:.4f} bf16 {a16:.4f}')
+    _log_parity('bf16_convergence', dict(steps=steps, loss_start=c32[0], loss_end_fp32=end32, loss_end_bf16=end16, absrel_fp32=a32, absrel_bf16=a16,
+                                         curve_fp32=c32[::10], curve_bf16=c16[::10]))
+    assert end32 < 0.7 * c32[0], 'the task must be learnable: the fp32 run did not converge'      # otherwise the comparison says nothing
+    assert abs(end16 - end32) <= 0.1 * end32, (end16, end32)
+    assert abs(a16 - a32) <= 0.03, (a16, a32)
+
+
 def test_config4_ddad_native_resolution_train_step(dev):
     """configs[3]: DepthFormer-SwinL + GEDepth-Adaptive at the native DDAD resolution 1x5x1216x1936 (per-camera height
     kwarg, loading.py:923-932): one full bf16 training step on the HIP path — finite losses, every parameter gets a finite
