@@ -179,6 +179,7 @@ def build_job(args, cfg, dev, rank, dtype):
         optimizer.step()
         return out
     step.batch = batch
+    step.ddp = ddp
     return step, per_gpu, optimizer
 
 
@@ -284,6 +285,17 @@ def main():
     loss = out['log_vars']['loss']
     note(f'timed region done: {1e3 * elapsed / args.steps:.2f} ms/step; H2D-inclusive pass')
     h2d_elapsed, h2d_bytes = h2d_inclusive(step, args.steps, dev, world) if not args.no_h2d else (None, 0)
+    # ---- gradient exchange: one extra step with per-bucket timing (outside the timed region: the trace synchronises the device)
+    ddp_info = step.ddp.describe()
+    if ddp_info['active']:
+        step.ddp.trace(True)
+        step()
+        fence()
+        step.ddp.trace(False)
+        ddp_info['trace'] = [dict(bucket=r['bucket'], MB=round(r['bytes'] / 2 ** 20, 2), params=r['params'], launch_ms=round(r['launch_ms'], 3),
+                                  done_ms=round(r['done_ms'], 3)) for r in step.ddp.bucket_trace()]
+        ddp_info['note'] = ('ms since the first gradient hook of that step; launch = all-reduce enqueued on RCCL while backward continues, '
+                            'done = wait() returned in finish(); an exchange that hides completes before the last bucket is launched')
     note('kernel-timing pass')
     # ---- pass 2: the same steps again with HIP events around every hand-written kernel (roofline object)
     prof, stages = [], []
@@ -315,12 +327,13 @@ def main():
                                'steps': args.steps, 'bytes_per_step': int(h2d_bytes),
                                'note': 'same steps, batch copied from pinned host memory every step (non-blocking, side stream, double-buffered: '
                                        'overlaps the previous step); `value` above is with resident inputs, as the bench contract defines it'}
+        res['ddp'] = ddp_info                                 # rank count as RCCL reports it, bucket layout, per-bucket overlap trace (N > 1)
         res['eager_fallbacks'] = dict(kernels.FALLBACKS)      # modules that took ATen where a HIP kernel exists: must be empty
         assert not kernels.FALLBACKS, f'eager fall-backs inside the measured step: {kernels.FALLBACKS}'
         if prof:
             # the MSDA backward is several kernels behind one entry point: rank its kernels individually (timed by HIP events
             # inside the library), so that `roofline` is about ONE kernel whose name rocprofv3 reports too
-            single = [r for r in prof if not (stages and r['name'].startswith(('msda_bwd[', 'msda_bwd_raw[')))] + stages
+            single = [r for r in prof if not (stages and r['name'].startswith(('msda_bwd[', 'msda_bwd_raw[', 'msda_bwd_value')))] + stages
             dom = max(single, key=lambda r: r['total_ms'])
             gbs = dom['bytes_per_launch'] / (dom['avg_us'] * 1e-6) / 1e9
             res['roofline'] = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
@@ -328,7 +341,7 @@ def main():
                                'avg_us': round(dom['avg_us'], 2), 'launches': dom['launches'],
                                'algorithmic_bytes_per_launch': int(dom['bytes_per_launch']),
                                'timed': f'HIP events on the launch stream, separate pass of {args.profile_steps} steps after the timed region'}
-            res['roofline']['traffic'] = pmc_traffic(dom['name'])
+            res['roofline']['traffic'] = pmc_traffic(dom['name'].split('[')[0])
             step_ms = 1e3 * elapsed / args.steps
             def krow(r):
                 row = {'name': r['name'], 'launches': r['launches'], 'avg_us': round(r['avg_us'], 2),

@@ -424,7 +424,7 @@ def msda_fwd_mm(value, raw, ref, spatial_shapes, order=None, want_loc=False, nH=
         assert order.dtype == torch.int32 and order.is_cuda and order.numel() == Nq and order.is_contiguous()
     base = hip.ptr(raw, name='raw')
     nbytes = value.numel() * 2 + raw.numel() * 2 + out.numel() * 2 + ((loc.numel() + attw.numel()) * 4 if want_loc else 0)
-    PROFILER.run(f'msda_fwd_mm[B{B} Nq{Nq} Nv{Nv}]', nbytes, lambda: hip.check(hip.lib().ge_msda_fwd_mm(
+    PROFILER.run(f'msda_mm_fwd_k[B{B} Nq{Nq} Nv{Nv}]', nbytes, lambda: hip.check(hip.lib().ge_msda_fwd_mm(
         hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), base, ld, base + n_off * 2, ld, ref.data_ptr(),
         ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(order), hip.ptr(loc), hip.ptr(attw), hip.ptr(out), B, Nv, Nq, nH, L, P,
         hip.dtype_code(value), hip.stream()), 'ge_msda_fwd_mm'))
@@ -460,7 +460,7 @@ class _MSDeformAttnMM(torch.autograd.Function):
         d_raw = torch.empty(B, Nq, ld, device=value.device, dtype=raw.dtype)
         base, dbase = hip.ptr(raw), hip.ptr(d_raw)
         nb_lw = value.numel() * 2 + raw.numel() * 2 + d_raw.numel() * 2 + d_out.numel() * 2
-        PROFILER.run(f'msda_bwd_lw_mm[B{B} Nq{Nq} Nv{Nv}]', nb_lw, lambda: hip.check(lib.ge_msda_bwd_lw_mm(
+        PROFILER.run(f'msda_mm_bwd_lw_k[B{B} Nq{Nq} Nv{Nv}]', nb_lw, lambda: hip.check(lib.ge_msda_bwd_lw_mm(
             hip.ptr(value), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
             hip.ptr(order), hip.ptr(d_out), dbase, ld, dbase + n_off * 2, ld, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
             'ge_msda_bwd_lw_mm'))

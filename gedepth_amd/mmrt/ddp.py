@@ -59,6 +59,14 @@ class FlatDDP(nn.Module):
                 for m in members:
                     self.bucket_of[m] = len(self.buckets) - 1
                 end, members = off, []
+        # the arena starts with the patch-embed / stage-0 parameters: built from the end, the LAST bucket would be a sliver (< 1 MB for
+        # Swin-T at 64 MiB buckets) whose collective starts when backward is already over — a latency-bound all-reduce that nothing
+        # overlaps.  A tail below a quarter of the bucket size joins its neighbour (the slices are contiguous).
+        if len(self.buckets) >= 2 and (self.buckets[-1][1] - self.buckets[-1][0]) * 4 < cap:
+            (lo2, _, m2), (_, hi1, m1) = self.buckets.pop(), self.buckets.pop()
+            self.buckets.append((lo2, hi1, m1 + m2))
+            for m in m1 + m2:
+                self.bucket_of[m] = len(self.buckets) - 1
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._next = 0
@@ -89,8 +97,18 @@ class FlatDDP(nn.Module):
         return time.perf_counter()
 
     def bucket_trace(self):
-        """[{bucket, bytes, params, launch_ms, done_ms}] of the latest finished step (needs GE_DDP_TRACE=1)."""
+        """[{bucket, bytes, params, launch_ms, done_ms}] of the latest finished step (needs GE_DDP_TRACE=1 or ``trace(True)``)."""
         return list(self.last_trace)
+
+    def trace(self, on=True):
+        """Switch the per-bucket timing on / off at run time (it synchronises the device in ``finish``: keep it out of timed regions)."""
+        self.trace_on = bool(on)
+
+    def describe(self):
+        """Static facts of the exchange for logs / bench.py: rank count as the process group reports it, backend, bucket layout."""
+        return dict(active=bool(self.active), world_size=int(self.world), backend=self.backend,
+                    wire_dtype='bf16' if self.grad_dtype is not None else 'fp32', n_buckets=len(self.buckets),
+                    bucket_MB=[round((hi - lo) * (2 if self.grad_dtype is not None else 4) / 2 ** 20, 2) for lo, hi, _ in self.buckets])
 
     def _make_hook(self, idx):
         def hook(param):
