@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) MSDA_LW_ATTR msda_bwd_lw_k(const T* __res
 // ---------------------------------------------------------------------------------------------------------
 // d_value without per-channel atomics: bin the sampling points by value tile, then accumulate each tile in REGISTERS.
 //
-// Measured on MI355X (scratch/ubench): the L2 executes fp32 atomics at ~1 dword/clock/channel (5.0 G 256-byte bursts/s
+// Measured on MI355X (tools/ubench/ubench): the L2 executes fp32 atomics at ~1 dword/clock/channel (5.0 G 256-byte bursts/s
 // chip-wide, independent of footprint and scope) and LDS fp32 atomics are slower still (ds_add_f32: ~170 cycles per
 // wave-instruction per CU).  The direct scatter needs 4 x 64 dword atomics per sampling point, which pins the
 // cross-attention of 8 images at ~140 ms.  Binning needs ONE integer (LDS) atomic per record:

@@ -39,7 +39,11 @@ def train_depther(model, dataset, cfg, distributed=False, validate=False, timest
     assert cfg.runner['type'] == 'IterBasedRunner'
     # numerics follow the config: the reference trains in fp32 (fp16_enabled = False, depth/models/depther/base.py:20), so a
     # reference config run through this drop-in stays fp32; bf16 autocast is an explicit choice (cfg.amp = 'bf16' / --bf16)
-    amp = torch.bfloat16 if cfg.get('amp', 'fp32') == 'bf16' else None
+    amp_name = cfg.get('amp', 'fp32')
+    if amp_name not in ('fp32', 'bf16'):
+        raise ValueError(f"cfg.amp must be 'fp32' (the reference's precision, default) or 'bf16' (autocast + bf16 shadow weights), got {amp_name!r}")
+    logger(f'precision: {amp_name}' + (' (bf16 autocast, fp32 master weights)' if amp_name == 'bf16' else ' (reference precision)'))
+    amp = torch.bfloat16 if amp_name == 'bf16' else None
     runner = IterBasedRunner(wrapped, optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta,
                              max_iters=cfg.runner['max_iters'], amp_dtype=amp)
     runner.batch_transform = batch_transform

@@ -175,6 +175,8 @@ class DepthFormerSwin(BaseModule):
                  depth=None, num_stages=None, with_cp=False, conv_strides=(1, 2, 2, 2), conv_dilations=(1, 1, 1, 1),
                  style='pytorch', conv_pretrained=None, USEPE=False, USE_PARAM_PE=False):
         super().__init__()
+        if with_cp:        # activation checkpointing would re-run DropPath with a fresh row of the one-draw bank (mmrt/bricks.py): refuse, do not mis-train
+            raise NotImplementedError('with_cp=True (activation checkpointing) is not supported: 288 GB of HBM make it unnecessary on MI355X')
         if num_stages not in (0, None):
             raise NotImplementedError('the ResNet branch (num_stages>0) is outside the GEDepth hot path')
         if USE_PARAM_PE:

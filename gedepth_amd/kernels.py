@@ -635,7 +635,7 @@ def residual_dropout(identity, tokens, p, seed=None):
     """``identity + F.dropout(tokens, p)`` for token matrices (B,N,C) in training mode (p > 0)."""
     vn = 8 if tokens.dtype == torch.bfloat16 else 4
     if not (tokens.is_cuda and tokens.dim() == 3 and tokens.dtype in (_f32, torch.bfloat16) and tokens.shape[2] % vn == 0 and identity.shape == tokens.shape
-            and 0.0 < p < 1.0):
+            and identity.dtype == tokens.dtype and 0.0 < p < 1.0):       # mixed dtypes: the eager composition and its type promotion
         return identity + torch.nn.functional.dropout(tokens, p, True)
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # host generator: follows torch.manual_seed, no device sync
@@ -857,7 +857,7 @@ class _Conv3x3(torch.autograd.Function):
                 dx = _conv3x3_launch(dy, wt, None, 0, 1.0)
             if ctx.needs_input_grad[1]:
                 Ci = x.shape[1]
-                # measured against MIOpen's wrw kernels (scratch/conv_time.py, CONV_SWINL=1 for the 2-image Swin-L shapes): the MFMA weight
+                # measured against MIOpen's wrw kernels (tools/ubench/conv_time.py, CONV_SWINL=1 for the 2-image Swin-L shapes): the MFMA weight
                 # gradient wins where the pixel count is large (176 x 560 x 8: 901 vs 1328 us for 576 -> 64); at 8 images it ties at
                 # 88 x 280 and loses on the coarse levels (few pixel tiles per K split, many output blocks: atomics + zero fill), but
                 # MIOpen's kernels get their parallelism from the batch: at 2 images per GPU (configs #3) ours wins 11 of 14 layers by
@@ -887,7 +887,9 @@ def conv3x3_ok(conv, x):
         return False
     bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16)
     # channels-last execution only (depth.models.utils.to_channels_last): an NCHW model keeps its layout end to end on the library path
-    return bf16 and _is_cl(x) and x.shape[0] * ((conv.out_channels + 63) // 64) <= 65535
+    # grid.z of the forward launch AND of the data-gradient launch (the same kernel with the channel roles swapped)
+    nt = max((conv.out_channels + 63) // 64, (conv.in_channels + 63) // 64)
+    return bf16 and _is_cl(x) and x.shape[0] * nt <= 65535
 
 
 def conv3x3(conv, x, bias=None, act=False, slope=1.0):

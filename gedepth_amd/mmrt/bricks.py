@@ -105,7 +105,7 @@ class ModuleList(BaseModule, nn.ModuleList):
 # ----------------------------------------------------------------------------------- layers
 def _split_k(tokens):
     """Number of K-chunks for the weight gradient of a Linear over ``tokens`` rows (0: leave it to the library)."""
-    # measured (scratch/wgrad_splitk2.py, MI355X): 12320 tokens x (1536 x 384) 70 us plain -> 44 us with 8 - 28 chunks, (384 x 384) 46 -> 29;
+    # measured (tools/ubench/wgrad_splitk2.py, MI355X): 12320 tokens x (1536 x 384) 70 us plain -> 44 us with 8 - 28 chunks, (384 x 384) 46 -> 29;
     # 3080 tokens: the plain GEMM is fastest (27 - 39 us); >= 49280 tokens: 2 - 3x from 32 - 44 chunks
     if tokens < 8192:
         return 0
@@ -119,7 +119,7 @@ class _LinearTokens(torch.autograd.Function):
     """``F.linear`` whose weight gradient is computed split-K.  dW = dY^T X has an output of at most 768 x 768 and a
     reduction over 5e4 - 8e5 tokens: the libraries run it as one GEMM on a handful of output tiles (hipBLASLt / rocBLAS,
     best tuned solution: 18 - 365 TFLOP/s on MI355X); as a batched GEMM over S token chunks plus an fp32 sum of the S
-    partial products it fills the chip (2 - 4x faster, scratch/wgrad_splitk.py) and the result is accumulated in fp32
+    partial products it fills the chip (2 - 4x faster, tools/ubench/wgrad_splitk.py) and the result is accumulated in fp32
     instead of being rounded to bf16 first.  Forward and input gradient are the library GEMMs unchanged."""
 
     @staticmethod
@@ -175,7 +175,7 @@ class _LinearBiasGelu(torch.autograd.Function):
             xc, wc = x.to(dt), lowp(weight, dt)
             # the bias rides in the library GEMM's epilogue (same addmm problem as before, i.e. the SAME tuned hipBLASLt solution of
             # gedepth_amd/tuning/tunableop_gfx950.csv: the bias-free mm variant of these shapes is not in the table and measured
-            # 0.4 ms/step slower, scratch/ab_bench.sh), so the kernels run with bias = NULL on y = x W^T + b
+            # 0.4 ms/step slower, tools/ubench/ab_bench.sh), so the kernels run with bias = NULL on y = x W^T + b
             y0 = F.linear(xc, wc, lowp(bias, dt))
             g = kernels.bias_gelu_fwd(y0, None)
         ctx.save_for_backward(xc, wc, y0)
@@ -475,23 +475,30 @@ class _DropPathBank:
     ``drop_path`` (one uniform per sample and layer; drawn in fp32, so the keep probability is exact to 2^-24)."""
 
     def __init__(self):
+        # layers are held by WEAK reference (a bank entry must not keep a discarded model alive); the keep probabilities are re-read
+        # from the live layers at every refill, so a later change of ``layer.drop_prob`` takes effect.  A recomputed forward
+        # (activation checkpointing) would draw a fresh row — ``with_cp`` is refused by the Swin blocks for that reason.
         self.layers, self.rows, self.used, self.key, self.keep = [], None, [], None, None
+        self.probs = None
         self.seed, self.offset = None, 0
 
     def scale(self, layer, batch, dtype, device):
         idx = getattr(layer, '_bank_index', None)
         key = (batch, device)
-        if idx is None or idx >= len(self.layers) or self.layers[idx] is not layer:
-            if len(self.layers) >= 512:                       # models come and go (tests): start over, live layers re-register
-                self.layers = []
+        if idx is None or idx >= len(self.layers) or self.layers[idx]() is not layer:
+            import weakref
+            self.layers = [r for r in self.layers if r() is not None]         # drop the entries of models that are gone
+            for i, r in enumerate(self.layers):
+                r()._bank_index = i
             idx = layer._bank_index = len(self.layers)
-            self.layers.append(layer)
+            self.layers.append(weakref.ref(layer))
             self.rows = self.keep = None
         gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()] if device.type == 'cuda' else None
         reseeded = gen is not None and (gen.initial_seed(), gen.get_offset() >= self.offset) != (self.seed, True)     # torch.manual_seed since the draw
         if self.rows is None or self.key != key or self.used[idx] or reseeded:
-            if self.keep is None or self.keep.device != device:
-                self.keep = torch.tensor([1.0 - l.drop_prob for l in self.layers], dtype=torch.float32).view(-1, 1).to(device)
+            probs = [1.0 - (r().drop_prob if r() is not None else 0.0) for r in self.layers]
+            if self.keep is None or self.keep.device != device or probs != self.probs:
+                self.keep, self.probs = torch.tensor(probs, dtype=torch.float32).view(-1, 1).to(device), probs
             u = torch.rand((len(self.layers), batch), dtype=torch.float32, device=device)
             self.rows = (self.keep + u).floor() / self.keep
             self.used = [False] * len(self.layers)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the round-3 fused passes: bench.py with everything on, then with one feature at a time switched to its two-pass
 # composition (GE_DISABLE, gedepth_amd/kernels.py).  Box-to-box spread of the same binary is 2-4 %, so only these same-session numbers
-# are quoted for small deltas.       gpurun -- 'bash scratch/ab_bench.sh'
+# are quoted for small deltas.       gpurun -- 'bash tools/ubench/ab_bench.sh'
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ARGS="--no-cpu-baseline --no-fp32 --no-h2d --no-kernel-timing --steps 30 --warmup 8"
 python bench.py $ARGS > /dev/null 2>&1          # warm caches

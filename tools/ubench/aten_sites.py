@@ -1,5 +1,5 @@
 """Which Python call sites launch the remaining ATen kernels of the bench step?  torch.profiler with stacks, grouped by the
-innermost repo frame; run on the GPU box: python scratch/aten_sites.py"""
+innermost repo frame; run on the GPU box: python tools/ubench/aten_sites.py"""
 import os
 import sys
 from collections import defaultdict

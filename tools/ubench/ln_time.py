@@ -1,4 +1,4 @@
-"""LayerNorm backward at the Swin shapes (optionally with another library: GE_LIB=...): python scratch/ln_time.py"""
+"""LayerNorm backward at the Swin shapes (optionally with another library: GE_LIB=...): python tools/ubench/ln_time.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 PMC passes over the hand-written 3x3 convolution kernels (scratch/conv_time.py): where do conv3x3_nhwc_k / conv3x3_wgrad_k wait?
+# rocprofv3 PMC passes over the hand-written 3x3 convolution kernels (tools/ubench/conv_time.py): where do conv3x3_nhwc_k / conv3x3_wgrad_k wait?
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_conv
@@ -7,7 +7,7 @@ mkdir -p $OUT
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16" \
            "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
   tag=$(echo $set | cut -d' ' -f1)
-  CONV_ONLY=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python $REPO/scratch/conv_time.py > $OUT/$tag.log 2>&1
+  CONV_ONLY=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python $REPO/tools/ubench/conv_time.py > $OUT/$tag.log 2>&1
 done
 REPO=$REPO python - <<'PY'
 import csv, glob, os, collections

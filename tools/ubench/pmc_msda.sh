@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INST
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
            "TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
   tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python $REPO/scratch/msda_time2.py > $OUT/$tag.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python $REPO/tools/ubench/msda_time2.py > $OUT/$tag.log 2>&1
 done
 REPO=$REPO python - <<'PY'
 import csv, glob, os, collections

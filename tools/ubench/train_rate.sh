@@ -1,7 +1,7 @@
 #!/bin/bash
 # SURVEY §8(f3) "done" criterion: tools/train.py on a KITTI-shaped tree with 2 loader workers per GPU — iteration time of the
 # device data pipeline (--gpu-pipeline) vs the reference's host pipeline, next to bench.py's resident-batch step time.
-#   gpurun -- 'bash scratch/train_rate.sh'        -> gpurun_out/train_rate_{gpu,host}.log
+#   gpurun -- 'bash tools/ubench/train_rate.sh'        -> gpurun_out/train_rate_{gpu,host}.log
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
 mkdir -p gpurun_out

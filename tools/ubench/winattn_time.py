@@ -1,5 +1,5 @@
 """Window-attention forward / backward times at the Swin-T stage shapes of the KITTI batch (8 x 352 x 1120).
-  python scratch/winattn_time.py [path/to/alternative/libgedepth_hip.so]"""
+  python tools/ubench/winattn_time.py [path/to/alternative/libgedepth_hip.so]"""
 import os
 import sys
 
