@@ -14,7 +14,11 @@
  *   - `dtype` selects the storage type of the activation tensors: GE_F32 or GE_BF16.
  *     Accumulation is always fp32.  Bias tables, sampling locations, attention weights and the
  *     whole ground-embedding path are fp32 regardless;
- *   - re-entrant: no mutable global state.
+ *   - thread-safe, and re-entrant except for three process-wide measurement / selection knobs that live in the library (mutex-guarded):
+ *     the kernel-selection mode of the deformable attention (ge_msda_mode: an A/B switch for tests and timing; kernels read it at
+ *     launch), the opt-in per-kernel timing of the composite MSDA backward (ge_msda_bwd_timing*: off by default, records nothing and
+ *     never synchronises when off), and two cached device properties (CU count, occupancy of the persistent MSDA kernels).  No
+ *     entry point keeps state that changes its RESULTS between calls.
  */
 #ifndef GEDEPTH_HIP_H
 #define GEDEPTH_HIP_H
