@@ -11,6 +11,8 @@ cross-attention reference points are input-independent for a fixed feature shape
 the embeddings / pixel-centre points are cached per shape, and the sampling core is one gather kernel
 (gedepth_amd/csrc/msda.hip) instead of mmcv's CUDA extension.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -84,7 +86,7 @@ class MultiScaleDeformableAttention(BaseModule):
         return self.output_proj(out)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, query_shapes=None, **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, query_shapes=None, query_order=None, **kwargs):
         """mmcv MultiScaleDeformableAttention.forward; ``query_shapes`` (extension, optional): the queries as (H, W) maps in
         raster order, e.g. ``spatial_shapes`` itself for self-attention — enables the 2-D tiled sampling kernels."""
         if value is None:
@@ -98,7 +100,7 @@ class MultiScaleDeformableAttention(BaseModule):
                 query = query + query_pos.to(query.dtype)
         if not self.batch_first:
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
-        out = self._attend(query, value, reference_points, spatial_shapes, key_padding_mask, query_shapes)
+        out = self._attend(query, value, reference_points, spatial_shapes, key_padding_mask, query_shapes, query_order)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         if self.training and self.dropout.p > 0 and out.is_cuda and out.dim() == 3 and self.batch_first:
@@ -205,8 +207,14 @@ class HAHIHeteroNeck(BaseModule):
         pos_flatten = torch.cat(poss, 1)                      # (1, N, C) fp32: broadcast over the batch inside the add
         if self.self_att:
             ref = self._pixel_centres(shapes, dev).expand(bs, -1, -1, -1)
+            # The MFMA decomposition (csrc/msda_mm.hip) on 4 x 8 patches of the token maps is available for the self-attention too
+            # (GE_MSDA_MM_SELF=1) but measured SLOWER than the LDS-window gather kernels here: the offset bias spreads the 8 points of a
+            # head over +-8 cells, so a 32-query patch reaches ~20 x 24 rows per level = 8 chunks of the 64-row coefficient image
+            # (forward 2.49 vs 1.63 ms, d_raw 2.48 vs 1.66 ms, step 53.0 vs 50.8 ms same-session, round 4)
+            order = (K.msda_tile_order(shapes, dev) if (os.environ.get('GE_MSDA_MM_SELF') == '1' and src_flatten.is_cuda
+                                                        and src_flatten.dtype == torch.bfloat16) else None)
             src = self.self_attn(src_flatten, value=None, identity=None, query_pos=pos_flatten,
-                                 reference_points=ref, spatial_shapes=shapes, query_shapes=shapes)
+                                 reference_points=ref, spatial_shapes=shapes, query_shapes=shapes, query_order=order)
         else:
             src = src_flatten
 

@@ -84,6 +84,7 @@ SIGNATURES = {
     'ge_conv3x3_nhwc_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_conv3x3_c1_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_conv3x3_c1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ge_gemm_nt': (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     'ge_nhwc_workspace': (_sz, [_i, _i]),
     'ge_aug_load': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     'ge_aug_depth': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

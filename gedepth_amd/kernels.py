@@ -1181,6 +1181,45 @@ def colsum(x):
     return out
 
 
+# ---- token GEMM (csrc/gemm.hip).  (K, N) -> (M_min, M_max) for which ge_gemm_nt beat the tuned hipBLASLt / rocBLAS solution on MI355X
+# (tools/ubench/gemm_time.py, profiles/r4_gemm_time.txt: ratio >= 1.1 there; everything else keeps the library GEMM).  GE_GEMM=all routes
+# every supported shape through the kernel (tests), GE_DISABLE=gemm none.
+GEMM_OWN = {
+    (96, 288): (60000, 400000),      # Swin stage-0 qkv: 61 vs 85 us at 197120 tokens
+    (96, 384): (60000, 400000),      # stage-0 FFN fc1 and d(fc2): 63 vs 76
+    (288, 96): (60000, 400000),      # stage-0 d(qkv): 62 vs 101
+    (192, 192): (20000, 100000),     # stage-1 proj and d(proj): 15 vs 20 at 49280
+    (384, 384): (6000, 25000),       # stage-2 proj and d(proj): 17 vs 20 at 12320
+    (512, 512): (150000, 400000),    # HAHI value / output projections of the 261800-token self-attention: 160 vs 178
+}
+_GEMM_ALL = os.environ.get('GE_GEMM', '') == 'all'
+
+
+def gemm_own(M, K, N):
+    """Should F.linear of an (M, K) bf16 token matrix with an (N, K) weight run on ge_gemm_nt?"""
+    if 'gemm' in DISABLED or K % 8 or N % 8 or M <= 0:
+        return False
+    if _GEMM_ALL:
+        return (M * K + K) * 2 < 2 ** 32 and (N * K + K) * 2 < 2 ** 32
+    r = GEMM_OWN.get((K, N))
+    return r is not None and r[0] <= M <= r[1]
+
+
+def gemm_nt(x2, w, bias=None):
+    """x2 (M, K) bf16 contiguous, w (N, K) bf16 contiguous, bias (N,) f32 or None -> (M, N) bf16 = x2 w^T + bias: fp32 accumulation,
+    bias added in fp32 before the single rounding (ge_gemm_nt).  Raises if the kernel refuses the problem: ask gemm_own first."""
+    M, K = x2.shape
+    N = w.shape[0]
+    assert x2.dtype == w.dtype == torch.bfloat16 and w.shape[1] == K and x2.is_contiguous() and w.is_contiguous()
+    if bias is not None:
+        assert bias.dtype == _f32 and bias.numel() == N and bias.is_contiguous()
+    out = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16)
+    PROFILER.run(f'gemm_nt[{M}x{K}->{N}]', 2 * (M * K + N * K + M * N), lambda: hip.check(hip.lib().ge_gemm_nt(
+        hip.ptr(x2, name='x'), K, hip.ptr(w, name='weight'), K, hip.ptr(bias), hip.ptr(out), N, M, N, K, hip.GE_BF16, hip.stream()), 'ge_gemm_nt'),
+        flops=2.0 * M * N * K)
+    return out
+
+
 def bias_gelu_fwd(y0, bias):
     """gelu(y0 + bias) over a (rows, C) matrix (the bias-free output of the FFN's first GEMM); bias fp32 (C) or None."""
     C = y0.shape[-1]

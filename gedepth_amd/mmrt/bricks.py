@@ -115,6 +115,30 @@ def _split_k(tokens):
     return 0
 
 
+def _linear_fwd(xc, wc, weight, bias, dt):
+    """y = xc wc^T + bias for the token Linears: ge_gemm_nt (csrc/gemm.hip) for the shapes where it beats the tuned library solution
+    (kernels.GEMM_OWN), the library GEMM with its bias epilogue otherwise.  `bias` is the fp32 master parameter: the own kernel adds it in
+    fp32 before the single rounding, the library epilogue adds the bf16 shadow."""
+    from .. import kernels
+    from .optim import lowp
+    K = xc.shape[-1]
+    M = xc.numel() // K
+    if (dt == torch.bfloat16 and xc.is_cuda and xc.is_contiguous() and wc.is_contiguous() and kernels.gemm_own(M, K, wc.shape[0])
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+        return kernels.gemm_nt(xc.reshape(M, K), wc, None if bias is None else bias.detach()).view(*xc.shape[:-1], wc.shape[0])
+    return F.linear(xc, wc, None if bias is None else lowp(bias, dt))
+
+
+def _linear_dx(dy2, wc):
+    """dx = dy2 wc (the input gradient of a token Linear): ge_gemm_nt on the transposed weight where it wins, else the library GEMM."""
+    from .. import kernels
+    M, N = dy2.shape
+    K = wc.shape[1]
+    if dy2.dtype == torch.bfloat16 and dy2.is_contiguous() and kernels.gemm_own(M, N, K):
+        return kernels.gemm_nt(dy2, wc.t().contiguous(), None)          # (K, N) weight image: <= 1.2 MB, one small transpose kernel
+    return dy2 @ wc
+
+
 class _LinearTokens(torch.autograd.Function):
     """``F.linear`` whose weight gradient is computed split-K.  dW = dY^T X has an output of at most 768 x 768 and a
     reduction over 5e4 - 8e5 tokens: the libraries run it as one GEMM on a handful of output tiles (hipBLASLt / rocBLAS,
@@ -128,7 +152,7 @@ class _LinearTokens(torch.autograd.Function):
         with torch.autocast('cuda', enabled=False):
             from .optim import lowp
             xc, wc = x.to(dt), lowp(weight, dt)
-            y = F.linear(xc, wc, None if bias is None else lowp(bias, dt))
+            y = _linear_fwd(xc, wc, weight, bias, dt)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (splits, x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return y
@@ -142,8 +166,10 @@ class _LinearTokens(torch.autograd.Function):
             dy2 = dy.to(wc.dtype).reshape(K, -1)
             x2 = xc.reshape(K, -1)
             dx = dw = db = None
+            if not dy2.is_contiguous():
+                dy2 = dy2.contiguous()
             if ctx.needs_input_grad[0]:
-                dx = (dy2 @ wc).reshape(xc.shape).to(x_dtype)
+                dx = _linear_dx(dy2, wc).reshape(xc.shape).to(x_dtype)
             if ctx.needs_input_grad[1]:
                 if splits:
                     M, N = dy2.shape[1], x2.shape[1]
@@ -176,7 +202,7 @@ class _LinearBiasGelu(torch.autograd.Function):
             # the bias rides in the library GEMM's epilogue (same addmm problem as before, i.e. the SAME tuned hipBLASLt solution of
             # gedepth_amd/tuning/tunableop_gfx950.csv: the bias-free mm variant of these shapes is not in the table and measured
             # 0.4 ms/step slower, tools/ubench/ab_bench.sh), so the kernels run with bias = NULL on y = x W^T + b
-            y0 = F.linear(xc, wc, lowp(bias, dt))
+            y0 = _linear_fwd(xc, wc, weight, bias, dt)
             g = kernels.bias_gelu_fwd(y0, None)
         ctx.save_for_backward(xc, wc, y0)
         ctx.meta = (splits, x.dtype, weight.dtype, bias.dtype)
@@ -196,7 +222,7 @@ class _LinearBiasGelu(torch.autograd.Function):
             x2 = xc.reshape(K, -1)
             dx = dw = None
             if ctx.needs_input_grad[0]:
-                dx = (dy2 @ wc).reshape(xc.shape).to(x_dtype)
+                dx = _linear_dx(dy2, wc).reshape(xc.shape).to(x_dtype)
             if ctx.needs_input_grad[1]:
                 if splits:
                     M, N = dy2.shape[1], x2.shape[1]

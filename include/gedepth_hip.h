@@ -34,7 +34,8 @@ enum { GE_F32 = 0, GE_BF16 = 1 };
 enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
 
 /* Library / device identification: returns the ABI version (3: round 3 added the raw-projection deformable-attention entry points,
- * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline). */
+ * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline; 4: round 4 added the MFMA
+ * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw) and the token GEMM ge_gemm_nt). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -412,6 +413,16 @@ int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, int N, int H
 int ge_conv3x3_c1_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin, int out_dtype, void* stream);
 int ge_conv3x3_c1_bwd(const void* x, const void* dy, const float* w, void* dx, float* dw, float* db, int N, int H, int W, int Cin,
                       int dy_dtype, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * Token GEMM (csrc/gemm.hip): C[M, N] = A[M, K] B[N, K]^T + bias[N] — torch.nn.functional.linear over a token matrix and,
+ * with B = the transposed weight, its input gradient.  Replaces the library GEMM behind the reference's nn.Linear layers of the
+ * Swin blocks (depth/models/backbones/depthformer_swin.py:193,221 qkv / proj, :451-459 FFN) and of mmcv's
+ * MultiScaleDeformableAttention in the HAHI neck (depth/models/necks/hahi.py:279-289,316-325).
+ *   A (M rows, leading dimension lda elements), B (N rows, ldb), C (M rows, ldc): bf16, 16-byte aligned, ld % 8 == 0, N % 8 == 0,
+ *   K % 8 == 0, operands < 4 GB each; bias (N) f32 or NULL; fp32 accumulation, bias added before the single rounding to bf16.
+ *   GE_ERR_UNSUPPORTED for anything else (the caller keeps the library GEMM for those). */
+int ge_gemm_nt(const void* A, long lda, const void* B, long ldb, const float* bias, void* C, long ldc, long M, int N, int K, int dtype,
+               void* stream);
 /* bytes of `workspace` for the channels-last column-sum users: K = 2 for ge_bn_act_nhwc_*, K = 1 for ge_bias_act_nhwc_bwd / ge_colsum */
 size_t ge_nhwc_workspace(int C, int K);
 

@@ -143,7 +143,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().ge_abi_version() == 3
+    assert hip.lib().ge_abi_version() == 4
     # argument validation happens before any launch, so these are safe without a GPU
     assert hip.lib().ge_bilinear_fwd(None, None, 1, 1, 4, 4, 8, 8, 0, 0, None) == 10001
     assert hip.lib().ge_window_attn_bwd_workspace(2, 11, 35, 3) > 0
@@ -268,3 +268,14 @@ def test_drop_path_bank_serves_every_layer_once_per_draw():
     late = DropPath(0.2)                                                 # a layer that shows up later joins the bank
     assert bank.scale(late, 6, torch.float32, dev).shape == (6,) and len(bank.layers) == 4
     assert bank.scale(layers[1], 4, torch.float32, dev).shape == (4,)    # another batch size: refill
+
+
+def test_gemm_policy_table():
+    """kernels.gemm_own: the shapes of the bench workload that go to ge_gemm_nt, and the refusals (host logic, no GPU)."""
+    from gedepth_amd import kernels
+    assert kernels.gemm_own(197120, 96, 288) and kernels.gemm_own(197120, 288, 96) and kernels.gemm_own(49280, 192, 192)
+    assert not kernels.gemm_own(788480, 512, 768)        # the library solution is faster there
+    assert not kernels.gemm_own(3080, 3072, 768)         # 39 tiles: no split-K in the kernel
+    assert not kernels.gemm_own(197120, 96, 292) and not kernels.gemm_own(0, 96, 288)
+    for (k, n), (lo, hi) in kernels.GEMM_OWN.items():
+        assert k % 8 == 0 and n % 8 == 0 and 0 < lo < hi

@@ -1818,3 +1818,87 @@ def test_layer_norm_with_skip_gradient(dev, dtypes):
     _, s4 = kernels.layer_norm_res(x4, wg, bg, 1e-5, ty)
     s4.backward(go_s.to(dev))
     assert torch.equal(x4.grad, go_s.to(dev))
+
+
+# ------------------------------------------------------------------------------ token GEMM (csrc/gemm.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(49280, 192, 192), (12320, 384, 1152), (1000, 520, 264), (257, 72, 8), (256, 64, 256), (255, 8, 8),
+                                   (3080, 3072, 768), (70000, 96, 288), (513, 136, 520)])
+@pytest.mark.parametrize('with_bias', [True, False])
+def test_gemm_nt_vs_float64(dev, shape, with_bias):
+    """ge_gemm_nt = F.linear on bf16 operands: every output element against float64 on the same bf16-rounded operands (one rounding of the
+    fp32 sum: 2^-9 relative + the fp32 accumulation error), M / N / K tails (M % 256, N % 256, K % 64 != 0), two launches bit-identical."""
+    from gedepth_amd import kernels
+    M, K, N = shape
+    g = torch.Generator(device='cpu').manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if with_bias else None
+    y = kernels.gemm_nt(x, w, b)
+    ref = x.double() @ w.double().t()
+    if with_bias:
+        ref = ref + b.double()
+    err = (y.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-2 * (K ** 0.5) * 2.0 ** -12 + 1e-6
+    bad = err > tol
+    assert not bool(bad.any()), (shape, int(bad.sum()), float(err.max()))
+    assert torch.equal(y, kernels.gemm_nt(x, w, b))
+    # padding rows / columns of the last tiles must not leak: a sentinel-framed output buffer stays intact
+    from gedepth_amd import hip
+    buf = torch.full((M + 2, N), 7.0, device=dev, dtype=torch.bfloat16)
+    rc = hip.lib().ge_gemm_nt(x.data_ptr(), K, w.data_ptr(), K, None if b is None else b.data_ptr(), buf[1:M + 1].data_ptr(), N, M, N, K,
+                              hip.GE_BF16, hip.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(buf[1:M + 1], y) and bool((buf[0] == 7).all()) and bool((buf[M + 1] == 7).all())
+
+
+@pytest.mark.gpu
+def test_gemm_nt_refuses_what_it_does_not_cover(dev):
+    from gedepth_amd import hip
+    x = torch.zeros(64, 64, device=dev, dtype=torch.bfloat16)
+    y = torch.zeros(64, 64, device=dev, dtype=torch.bfloat16)
+    lib, st = hip.lib(), hip.stream()
+    assert lib.ge_gemm_nt(x.data_ptr(), 64, x.data_ptr(), 64, None, y.data_ptr(), 64, 64, 64, 64, hip.GE_F32, st) == 10002      # fp32 storage
+    assert lib.ge_gemm_nt(x.data_ptr(), 64, x.data_ptr(), 64, None, y.data_ptr(), 64, 64, 60, 64, hip.GE_BF16, st) == 10002     # N % 8
+    assert lib.ge_gemm_nt(x.data_ptr(), 64, x.data_ptr(), 64, None, y.data_ptr(), 64, 64, 64, 60, hip.GE_BF16, st) == 10002     # K % 8
+    assert lib.ge_gemm_nt(x.data_ptr() + 2, 64, x.data_ptr(), 64, None, y.data_ptr(), 64, 32, 64, 64, hip.GE_BF16, st) == 10002  # alignment
+    assert lib.ge_gemm_nt(None, 64, x.data_ptr(), 64, None, y.data_ptr(), 64, 64, 64, 64, hip.GE_BF16, st) == 10001
+    assert lib.ge_gemm_nt(x.data_ptr(), 64, x.data_ptr(), 64, None, y.data_ptr(), 64, 0, 64, 64, hip.GE_BF16, st) == 0          # empty: no launch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gelu', [False, True])
+def test_token_linear_on_own_gemm_matches_library_path(dev, gelu, monkeypatch):
+    """bricks.linear_tokens / linear_bias_gelu with every GEMM routed through ge_gemm_nt (forward and input gradient) against the same
+    module on the library GEMMs and against float64 autograd on the bf16-rounded operands."""
+    from gedepth_amd import kernels
+    from gedepth_amd.mmrt import bricks
+    torch.manual_seed(5)
+    M, K, N = 9000, 96, 288
+    x0 = torch.randn(3, M // 3, K, device=dev)
+    lin = torch.nn.Linear(K, N).to(dev)
+    dy = torch.randn(3, M // 3, N, device=dev).to(torch.bfloat16)
+
+    def run(own):
+        monkeypatch.setattr(kernels, '_GEMM_ALL', own)
+        monkeypatch.setattr(kernels, 'GEMM_OWN', {} if not own else kernels.GEMM_OWN)
+        x = x0.clone().requires_grad_(True)
+        lin.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = bricks.linear_bias_gelu(x, lin.weight, lin.bias) if gelu else bricks.linear_tokens(x, lin.weight, lin.bias)
+        y.backward(dy)
+        return y.detach(), x.grad.detach(), lin.weight.grad.detach().clone(), lin.bias.grad.detach().clone()
+    own, libp = run(True), run(False)
+    xd = x0.to(torch.bfloat16).double().requires_grad_(True)
+    wd = lin.weight.detach().to(torch.bfloat16).double().requires_grad_(True)
+    bd = lin.bias.detach().double().requires_grad_(True)
+    yd = F.linear(xd, wd, bd)
+    if gelu:
+        yd = F.gelu(yd)
+    yd.backward(dy.double())
+    ref = (yd.detach(), xd.grad, wd.grad, bd.grad)
+    for name, a, l, r in zip(('y', 'dx', 'dw', 'db'), own, libp, ref):
+        scale = float(r.abs().max())
+        e_own, e_lib = float((a.double() - r).abs().max()) / scale, float((l.double() - r).abs().max()) / scale
+        assert e_own <= max(1.5 * e_lib, 2.0 ** -7), (name, e_own, e_lib)
