@@ -1633,14 +1633,21 @@ def test_upsum_matches_pe_trunk_composition(dev, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('act', [False, True])
-@pytest.mark.parametrize('geom', [(2, 64, 64, 16, 40), (1, 160, 64, 13, 37), (2, 96, 96, 9, 33), (1, 288, 192, 22, 70), (1, 64, 128, 8, 32), (2, 32, 32, 3, 5)])
-def test_conv3x3_mfma_vs_conv2d(dev, geom, act):
+@pytest.mark.parametrize('geom', [(2, 64, 64, 16, 40), (1, 160, 64, 13, 37), (2, 96, 96, 9, 33), (1, 288, 192, 22, 70), (1, 64, 128, 8, 32), (2, 32, 32, 3, 5),
+                                  (1, 576, 64, 176, 560)])
+@pytest.mark.parametrize('variant', ['1', '2'])
+def test_conv3x3_mfma_vs_conv2d(dev, geom, act, variant, monkeypatch):
     """kernels.conv3x3 (ge_conv3x3_nhwc_fwd: implicit-GEMM 3x3 convolution on v_mfma_f32_32x32x16_bf16 with the bias + LeakyReLU epilogue;
     its data gradient = the same kernel on flipped / transposed weights; weight gradient = ge_conv3x3_nhwc_wgrad, transposing LDS reads) against F.conv2d in float64 on the
     same bf16-rounded operands: y, d_x, d_w, d_bias; tiles that hang over the right / bottom border, several 64-channel output tiles, a
-    partial one (96), maps smaller than one tile."""
+    partial one (96), maps smaller than one tile, and the largest layer of the bench step (1 x 576 -> 64 @176 x 560: forward, data gradient
+    and the K-split weight gradient with its fp32 atomic flush).  Both forward kernels: the register-staged 8 x 32 tile (variant 1) and the
+    LDS-DMA 16 x 32 tile (variant 2, round 4) — selected through GE_CONV3X3, which the library reads per call."""
     from gedepth_amd import kernels
+    monkeypatch.setenv('GE_CONV3X3', variant)
     N, Ci, Co, H, W = geom
+    if H * W > 50000 and act:
+        pytest.skip('the bench-shape case runs once per kernel variant (float64 reference on the CPU: ~20 s)')
     g = gen(51)
     x = torch.randn(N, Ci, H, W, generator=g).bfloat16()
     w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).bfloat16()
