@@ -204,7 +204,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_nhwc_dma_k(const bf16_t* __res
     const int ch = wv + 8 * i;                               // KB of the buffer) keep the K loop free of branches: with a branch per DMA the
     const unsigned char* base = ch < CD_HCH ? xn : wb;       // compiler waits for ALL outstanding LDS reads at every join
     const unsigned char* p = goff[i] == ~0u ? (const unsigned char*)cd_zero16 : base + (size_t)(goff[i] + (unsigned)(c0 * 2));
-    __builtin_amdgcn_global_load_lds(CD_GLB(p), CD_LDS(void, smem + buf * CD_BUF + ch * 1024), 16, 0, 0);
+    // inline asm instead of __builtin_amdgcn_global_load_lds: see csrc/gemm.hip (the builtin turns every LDS wait near it into lgkmcnt(0))
+    const unsigned ldst = (unsigned)(uintptr_t)CD_LDS(unsigned char, smem + buf * CD_BUF + ch * 1024);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(ldst), "v"(p) : "memory", "m0");
   };
 
   cv_f32x16 acc[2][2];

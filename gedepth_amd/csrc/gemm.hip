@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(512, 1) gemm_nt_k(GemmArgs a) {
     const int k0 = ks * GM_BK;
     const unsigned char* p = (k0 + lpk[c] >= a.K) ? (const unsigned char*)gm_zero16      // K tail: pieces past K come from the zero block
                                                   : (const unsigned char*)basep + (size_t)(rowoff + (unsigned)(k0 * 2));
-    __builtin_amdgcn_global_load_lds(GM_GLB(p), GM_LDS(void, slot + wv * 4096 + c * 1024), 16, 0, 0);
+    // inline asm, not __builtin_amdgcn_global_load_lds: the compiler books a FLAT-class instruction on BOTH counters, and with one of
+    // them among the ds_reads every LDS wait of the K loop becomes lgkmcnt(0) — the fragment reads issued a moment ago included.  The
+    // hardware counts an LDS-DMA on vmcnt only; all vmcnt waits of this kernel are explicit.
+    const unsigned ldst = (unsigned)(uintptr_t)GM_LDS(unsigned char, slot + wv * 4096 + c * 1024);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(ldst), "v"(p) : "memory", "m0");
   };
   unsigned char* const aslots = smem;
   unsigned char* const bslots = smem + 3 * GM_TILE;
