@@ -106,6 +106,7 @@ struct MsdaBins { int first_tile[MSDA_MAX_L + 1]; int ntx[MSDA_MAX_L]; };   // t
 
 struct MsdaWs {            // device workspace carved by the host wrapper
   int* cnt; int* seg_hist; int* chunk_first; long* offset; int* ctrl; int4* entries;   // ctrl[0] = total chunks, ctrl[2+x] = next chunk of XCD x's share
+  int* order;              // drain work order: item -> chunk id (msda_order_k), grouped by (image, head, query range of the chunk's first record)
 };
 
 // bf16 drain of the binned d_value on the matrix cores (msda_drain_mfma.hip); tr = use ds_read_b64_tr_b16 for the B operand

@@ -699,6 +699,50 @@ __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
   if (threadIdx.x >= 1 && threadIdx.x < 2 + MSDA_XCDS) ws.ctrl[threadIdx.x] = 0;      // per-XCD work cursors
 }
 
+// Work order of the drain.  The records of a bin are laid out unit by unit, i.e. sorted by the QUERY RANGE r they come from, and a chunk
+// is MSDA_CHUNK consecutive records of one bin.  Drained in bin order — (image, head, level, tile) — the waves in flight on an XCD (3
+// workgroups x 4 waves x 32 CUs = 384 chunks) walk a whole level of the (image, head) at a time, and their records point at gradient
+// rows all over the 12.6 MB of d_out rows that (image, head) has (KITTI cross-attention) — three times the XCD's L2, and every level
+// fetches them again: 6.8 GB of re-fetched rows per launch (rocprofv3 FETCH_SIZE, profiles/pmc_traffic.json) for 0.8 GB of d_out.
+// Here the chunks of an (image, head) are listed range by range instead: item -> chunk id with all chunks whose FIRST record comes from
+// query range 0 first (tiles of all four levels), then range 1, ...  What is in flight then reads the d_out rows of one or two ranges
+// (Nq / R rows x 128 B = 1.6 MB each at R = 8), which stay in L2 across the levels.  One workgroup per (image, head): count the
+// chunks per range in LDS, exclusive scan, place.  The order inside a range is the order the LDS atomics resolve in (any order is correct:
+// chunks of one bin meet in d_value through fp32 atomics either way).
+#define MSDA_MAX_R 512
+__global__ void __launch_bounds__(1024) msda_order_k(MsdaWs ws, int ntiles, int R, int grouped) {
+  __shared__ int s_cnt[MSDA_MAX_R], s_base[MSDA_MAX_R];
+  const int bh = blockIdx.x;
+  for (int i = threadIdx.x; i < R; i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  const int* seg = ws.seg_hist + (long)bh * R * ntiles;          // [r][tile]: absolute first slot of range r in the bin (after msda_segscan_k)
+  const int first = ws.chunk_first[bh * ntiles];
+  if (!grouped) {                                                 // bin order (mode bit 6 off: A/B runs)
+    const int last = ws.chunk_first[(bh + 1) * ntiles];
+    for (int i = first + threadIdx.x; i < last; i += 1024) ws.order[i] = i;
+    return;
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int tile = threadIdx.x; tile < ntiles; tile += 1024) {
+      const int bin = bh * ntiles + tile;
+      const int c0 = ws.chunk_first[bin], nch = ws.chunk_first[bin + 1] - c0;
+      const long off0 = ws.offset[bin];
+      int r = 0;
+      for (int c = 0; c < nch; ++c) {
+        const long slot = off0 + (long)c * MSDA_CHUNK;
+        while (r + 1 < R && seg[(long)(r + 1) * ntiles + tile] <= slot) ++r;        // range of the chunk's first record
+        const int k = atomicAdd(&s_cnt[r], 1);
+        if (pass) ws.order[first + s_base[r] + k] = c0 + c;
+      }
+    }
+    __syncthreads();
+    if (pass == 0) {
+      if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < R; ++i) { s_base[i] = run; run += s_cnt[i]; s_cnt[i] = 0; } }
+      __syncthreads();
+    }
+  }
+}
+
 // drain: a wave owns one chunk (<= MSDA_CHUNK records of one tile) and accumulates the tile in 32 VGPRs per lane
 // (lane == channel).  History (8 x 352 x 1120 cross-attention): v1 consumed (point, corner) entries in arrival order with
 // `acc[pos] += g * coef`, pos a dynamic register index: 6 VALU + 5 SALU per entry, VALU-issue bound, 12.5 ms.  v2 sorted
@@ -747,6 +791,7 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
       ++probe;
     }
     if (item < 0) break;
+    item = ws.order[item];                                // work order -> chunk id (msda_order_k)
     int lo = 0, hi = nbins;                               // largest bin with chunk_first[bin] <= item
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_first[mid] <= item) lo = mid; else hi = mid; }
     const int bin = lo;
@@ -909,8 +954,10 @@ static size_t msda_ws_layout(int nbins, long seg_hist_ints, long max_entries, ch
   auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_cnt = carve((size_t)nbins * 4), o_chk = carve((size_t)(nbins + 1) * 4);
   const size_t o_off = carve((size_t)(nbins + 1) * 8), o_ctrl = carve(64), o_sh = carve((size_t)seg_hist_ints * 4);
+  const size_t o_ord = carve((size_t)(nbins + max_entries / MSDA_CHUNK + 1) * 4);       // chunks <= bins + records / MSDA_CHUNK
   const size_t o_ent = carve((size_t)max_entries * 16);
   if (ws) {
+    ws->order = (int*)(base + o_ord);
     ws->cnt = (int*)(base + o_cnt); ws->chunk_first = (int*)(base + o_chk); ws->offset = (long*)(base + o_off);
     ws->ctrl = (int*)(base + o_ctrl); ws->seg_hist = (int*)(base + o_sh); ws->entries = (int4*)(base + o_ent);
   }
@@ -937,7 +984,7 @@ static MsdaPlan msda_plan(const MsdaBins& bins, int B, int Nq, int nH, int L, in
   pl.nbins = (int)nbins;
   const size_t hist_bytes = (size_t)pl.ntiles * 4;
   pl.ok = nbins < (1L << 30) && Nq < (1 << 24) && pl.max_entries < (1L << 31) && hist_bytes <= 60 * 1024 && B <= 65535 &&
-          ((long)Nq / R + 1) * L * P < (1L << 31) && (long)B * nH * R * pl.ntiles < (1L << 31);
+          ((long)Nq / R + 1) * L * P < (1L << 31) && (long)B * nH * R * pl.ntiles < (1L << 31) && R <= MSDA_MAX_R;
   return pl;
 }
 static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
@@ -955,11 +1002,12 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
 // Kernel selection: bit 0 = LDS-window forward, bit 1 = LDS-window d_loc / d_attw (both need the query geometry), bit 2 =
 // owner-lane tap arithmetic in the window kernels, bit 3 = head-major work order in the streaming kernels; the
 // streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
-// bit 4 = bf16 d_value drain on the matrix cores (msda_drain_mfma.hip), bit 5 = its B operand through ds_read_b64_tr_b16.
-static int g_msda_mode = 13 | 16 | 32;   // window forward + owner-lane taps + head-major streaming d_loc/d_attw + MFMA drain (measured best)
+// bit 4 = bf16 d_value drain on the matrix cores (msda_drain_mfma.hip), bit 5 = its B operand through ds_read_b64_tr_b16,
+// bit 6 = drain work order grouped by query range (msda_order_k) instead of bin order.
+static int g_msda_mode = 13 | 16 | 32 | 64;   // window forward + owner-lane taps + head-major streaming d_loc/d_attw + MFMA drain + range-grouped drain order (measured best)
 extern "C" int ge_msda_mode(int mode) {
   const int old = g_msda_mode;
-  if (mode >= 0) g_msda_mode = mode & 63;
+  if (mode >= 0) g_msda_mode = mode & 127;
   return old;
 }
 
@@ -1145,6 +1193,8 @@ static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* qu
   GE_LAUNCH_CHECK();
   msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.ntiles, pl.R, nbins);
   GE_LAUNCH_CHECK();
+  msda_order_k<<<(unsigned)(B * nH), 1024, 0, s>>>(ws, pl.ntiles, pl.R, (g_msda_mode & 64) != 0);
+  GE_LAUNCH_CHECK();
   msda_mark(ev, 3, s);
   msda_hist_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.R, B);
   GE_LAUNCH_CHECK();
@@ -1222,6 +1272,8 @@ extern "C" int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw,
   msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
   GE_LAUNCH_CHECK();
   msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.ntiles, pl.R, nbins);
+  GE_LAUNCH_CHECK();
+  msda_order_k<<<(unsigned)(B * nH), 1024, 0, s>>>(ws, pl.ntiles, pl.R, (g_msda_mode & 64) != 0);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 3, s);
   msda_hist_raw_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B);

@@ -122,7 +122,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
         if os.environ.get('GE_MSDA_MODE'):           # kernel-selection knob of the deformable attention (kernels.msda_mode), e.g.
-            handle.ge_msda_mode(int(os.environ['GE_MSDA_MODE']))      # 60 = default without the bf16-tap-weight window forward
+            handle.ge_msda_mode(int(os.environ['GE_MSDA_MODE']))      # 124 = default without the bf16-tap-weight window forward
     return _lib
 
 

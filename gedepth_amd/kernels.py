@@ -163,8 +163,8 @@ def _query_grid(query_shapes, Nq):
 def msda_mode(mode=-1):
     """Kernel-selection knob of the deformable-attention ops; returns the previous mode.  Bits: 0 window (LDS-staged) forward,
     1 window d_loc / d_attw, 2 owner-lane tap arithmetic in the window kernels, 3 head-major work order of the streaming kernels,
-    4 bf16 d_value drain on MFMA, 5 its operand reads through ds_read_b64_tr_b16.  Default 61; ``GE_MSDA_MODE`` in the environment
-    sets it at library load (e.g. 60: streaming forward with exact fp32 tap weights for accuracy-parity runs in bf16)."""
+    4 bf16 d_value drain on MFMA, 5 its operand reads through ds_read_b64_tr_b16, 6 drain work order grouped by query range.  Default 125;
+    ``GE_MSDA_MODE`` in the environment sets it at library load (e.g. 124: streaming forward with exact fp32 tap weights for accuracy-parity runs in bf16)."""
     return int(hip.lib().ge_msda_mode(int(mode)))
 
 

@@ -327,12 +327,13 @@ def test_msda_window_kernels(dev, case, dtype):
     stream = run(0, qshapes)
     stream_hm = run(8, qshapes)                             # streaming kernels, head-major work order
     mix = run(13, qshapes)                                  # window forward, streaming head-major backward, VALU drain
-    default = run(61, qshapes)                              # the default: the same + bf16 d_value drain on MFMA (transposing LDS reads)
+    bin_order = run(61, qshapes)                            # the same + bf16 d_value drain on MFMA (transposing LDS reads), chunks drained in bin order
+    default = run(125, qshapes)                             # the default: + drain work order grouped by query range (msda_order_k)
     mfma_plain = run(29, qshapes)                           # MFMA drain with plain 16-bit LDS reads for the B operand
     names = ('out', 'd value', 'd loc', 'd attw')
     # same arithmetic per (query, head): the decompositions agree to the order of the 8-lane / 16-lane reductions
     for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major'), (mix, 'mode 13'),
-                   (default, 'default mode 61'), (mfma_plain, 'mode 29')):
+                   (bin_order, 'mode 61'), (default, 'default mode 125'), (mfma_plain, 'mode 29')):
         for a, b, n in zip(w, stream, names):
             if dtype == 'f32':
                 close_scaled(a, b, rel=2e-5, what=f'{tag} vs streaming: {n}')
@@ -397,7 +398,7 @@ def test_msda_bf16(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', [61, 29, 13, 0, 8, 7])
+@pytest.mark.parametrize('mode', [125, 61, 29, 13, 64, 0, 8, 7])
 @pytest.mark.parametrize('binned', [True, False])
 def test_msda_bf16_gradients_vs_oracle(dev, mode, binned, monkeypatch):
     """bf16 storage path against the fp32 CPU oracle evaluated on the SAME bf16-rounded value / gradient rows: d_loc and d_attw are
@@ -428,7 +429,7 @@ def test_msda_bf16_gradients_vs_oracle(dev, mode, binned, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', [61, 29, 13])
+@pytest.mark.parametrize('mode', [125, 61, 29, 13, 77])
 def test_msda_drain_many_records_per_tile(dev, mode):
     """d_value when a value tile collects far more than one chunk of records (4096): 4000 queries x 8 points land on a level of
     2 x 4 tiles, so every bin is drained by several waves whose partial tiles meet through fp32 atomics; the last block of a
@@ -497,8 +498,8 @@ def test_msda_raw_fused_prepare_and_sampling(dev, dtype, case):
     arr = (ctypes.c_int * 8)(*[x for hw in shapes for x in hw])
     qa = (ctypes.c_int * (2 * len(qshapes)))(*[x for hw in qshapes for x in hw])
     sup = hip.lib().ge_msda_raw_supported(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(qa, ctypes.c_void_p), len(qshapes), B, nv, nq, nH, L, P)
-    assert sup == 1                                            # the fused kernels are what `run(61)` exercises
-    fused = run(61)
+    assert sup == 1                                            # the fused kernels are what `run(125)` exercises
+    fused = run(125)
     composed = run(60)                                         # mode without the window forward: prepare pass + streaming kernels
     n_off = nH * L * P * 2
     names = ('out', 'd value', 'd raw', 'd ref')

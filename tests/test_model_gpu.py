@@ -522,6 +522,8 @@ def test_config3_swinl_adaptive_full_shape_bf16_step_vs_fp32(dev):
     g32 = _grad_vector(model)
     msda_names = [n for n, _ in model.named_parameters() if 'sampling_offsets' in n or 'attention_weights' in n]
     named32 = {n: p.grad.detach().double().flatten().clone() for n, p in model.named_parameters() if n in msda_names}
+    all32 = {n: p.grad.detach().double().flatten().clone() for n, p in model.named_parameters()
+             if n.startswith(('pe_mask_neck.', 'dynamic_pe_neck.'))}
     for p in model.parameters():
         p.grad = None
     optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
@@ -553,7 +555,24 @@ def test_config3_swinl_adaptive_full_shape_bf16_step_vs_fp32(dev):
     # Seen over eight runs of this test on the same build: 0.42, 0.78, 0.78, 0.79, 0.86, 0.87, 0.87, 0.89 for that tensor (fp32 atomics in
     # the weight-gradient / d_value reductions make the run-to-run rounding differ) while the global cosine stayed in 0.995 - 0.999: the
     # cross-attention offset tensors are REPORTED (parity_e2e.json), the assertions are on what carries signal.
-    assert torch.isfinite(g16).all() and cos >= 0.99 and 0.95 <= nrm <= 1.05, (cos, nrm, worst)
+    # Global norm ratio: bound 0.9 - 1.1 as for config #2.  Round 4 localised why this quantity moves by several per cent between
+    # identical bf16 runs (1.007 ... 1.059 over six runs of one build, tools/ubench/diag_cfg3.py, profiles/r4_config3_gradient_diag.txt):
+    # the synthetic batch has valid ground truth above the horizon, where the ground embedding is zero and pred = relu(c) (1 - y) + 1e-3;
+    # SigLoss' d/dpred ~ 1 / pred makes the ~100 pixels whose regressor pre-activation c is barely positive carry 84 % of |dL/dc|^2,
+    # and at those pixels 1 / (c (1 - y) + 2e-3) changes by a factor under a 1e-2 perturbation of c (bf16 activations; the order of fp32
+    # atomics in the forward: loss differs by 4e-5 between identical runs).  The weight gradients still agree in direction (bulk pixels
+    # add coherently: decode head cosine 0.997 - 0.9998) but their norm carries that heavy-tailed term.  What pins the SCALE of the
+    # loss gradient instead is the ground-attention branch: it receives the same dL/dpred through d pe / d y, which has no such
+    # singularity — asserted below to 1 % in norm and 1e-4 in direction (measured 0.997 - 1.0004, cosine >= 0.99996).
+    assert torch.isfinite(g16).all() and cos >= 0.99 and 0.9 <= nrm <= 1.1, (cos, nrm, worst)
+    pe_names = [n for n, _ in model.named_parameters() if n.startswith(('pe_mask_neck.', 'dynamic_pe_neck.'))]
+    g16_pe = torch.cat([dict(model.named_parameters())[n].grad.detach().double().flatten() for n in pe_names])
+    g32_pe = torch.cat([all32[n] for n in pe_names])
+    cos_pe = torch.nn.functional.cosine_similarity(g16_pe, g32_pe, dim=0).item()
+    nrm_pe = (g16_pe.norm() / g32_pe.norm()).item()
+    print(f'   ground-attention branch (pe_mask_neck + dynamic_pe_neck): cosine {cos_pe:.6f}, |g_bf16|/|g_fp32| {nrm_pe:.5f}')
+    _log_parity('config3_bf16_vs_fp32_pe_branch', dict(grad_cosine=cos_pe, grad_norm_ratio=nrm_pe))
+    assert cos_pe >= 0.9999 and 0.99 <= nrm_pe <= 1.01, (cos_pe, nrm_pe)
     cross_offsets = [n for n in per if 'multi_att.sampling_offsets' in n]
     assert all(per[n] > 0.2 for n in cross_offsets), per
     assert all(c >= 0.8 for n, c in per.items() if n not in cross_offsets), per

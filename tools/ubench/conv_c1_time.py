@@ -1,6 +1,6 @@
 """ge_conv3x3_c1_fwd / _bwd (64 -> 1, 3x3) against MIOpen at the bench shape: python tools/ubench/conv_c1_time.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from gedepth_amd import hip

@@ -27,9 +27,35 @@ to_channels_last(model)
 model.neck.multi_att.dropout.p = 0.0
 model.neck.self_attn.dropout.p = 0.0
 batch = synthetic_batch(2, 352, 1120, seed=1234, device=dev)
+
+# the regressor's pre-activation c (decode_head.depth_pred: pred = relu(c) (1 - y) + pe + min_depth) and its gradient, per pass
+from gedepth_amd import kernels as K
+CAP = {}
+_c1 = K.conv3x3_c1
+
+
+def _c1_cap(conv, feat, **kw):
+    c = _c1(conv, feat, **kw)
+    CAP['c'] = c.detach().float().clone()
+    if c.requires_grad:
+        c.register_hook(lambda g: CAP.__setitem__('dc', g.detach().float().clone()))
+    return c
+
+
+K.conv3x3_c1 = _c1_cap
+
+
+def _module_cap(mod, inp, out):                             # the library path of the same layer (fp32 pass when the HIP kernel declines)
+    CAP['c'] = out.detach().float().clone()
+    if out.requires_grad:
+        out.register_hook(lambda g: CAP.__setitem__('dc', g.detach().float().clone()))
+
+
+model.decode_head.conv_depth.register_forward_hook(_module_cap)
 ref = model.train_step(batch, None)
 ref['loss'].backward()
 g32 = {n: p.grad.detach().double().flatten().clone() for n, p in model.named_parameters()}
+cap32 = dict(CAP)
 for p in model.parameters():
     p.grad = None
 optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
@@ -45,6 +71,22 @@ for r in range(runs):
     dot = sum((g16[n] * g32[n]).sum().item() for n in g32)
     print(f'run {r}: GE_DISABLE={os.environ.get("GE_DISABLE", "")} losses fp32 {dict(ref["log_vars"])} bf16 {dict(out["log_vars"])}')
     print(f'  |g16|/|g32| {(n16 / n32) ** 0.5:.4f}  cosine {dot / (n16 * n32) ** 0.5:.5f}')
+    c32, c16, d32, d16 = cap32['c'].flatten(), CAP['c'].flatten(), cap32['dc'].flatten().double(), CAP['dc'].flatten().double()
+    on32, on16 = c32 > 0, c16 > 0
+    e32, e16 = d32.pow(2).sum().item(), d16.pow(2).sum().item()
+    print(f'  regressor pre-activation c: {c32.numel()} px, active fp32 {on32.sum().item()} bf16 {on16.sum().item()}, '
+          f'off->on {(~on32 & on16).sum().item()} on->off {(on32 & ~on16).sum().item()}; |c| quantiles (fp32) '
+          f'{[round(v, 5) for v in c32.abs().quantile(torch.tensor([0.1, 0.5, 0.9], device=dev)).tolist()]}')
+    print(f'  |dc|^2: fp32 {e32:.4e} bf16 {e16:.4e} (ratio of norms {(e16 / e32) ** 0.5:.4f}); share of fp32 |dc|^2 in its top 100 px '
+          f'{d32.pow(2).topk(100).values.sum().item() / e32:.3f}, top 1000 px {d32.pow(2).topk(1000).values.sum().item() / e32:.3f}; '
+          f'bf16 |dc|^2 on px that are off in fp32 {d16[~on32].pow(2).sum().item() / e16:.4f}, fp32 |dc|^2 on px off in bf16 '
+          f'{d32[~on16].pow(2).sum().item() / e32:.4f}')
+    top = d32.abs().topk(8).indices
+    print('  top 8 px by |dc| (fp32): c fp32 / c bf16 / dc fp32 / dc bf16: ' + '; '.join(
+        f'{c32[i].item():.4f} / {c16[i].item():.4f} / {d32[i].item():+.3e} / {d16[i].item():+.3e}' for i in top.tolist()))
+    both = on32 & on16
+    print(f'  on px active in both: |dc16|/|dc32| {(d16[both].pow(2).sum() / d32[both].pow(2).sum()).sqrt().item():.4f}, cosine '
+          f'{(d16[both] * d32[both]).sum().item() / (d16[both].norm() * d32[both].norm()).item():.5f}')
     rows = []
     mods = collections.defaultdict(lambda: [0.0, 0.0, 0.0])
     for n in g32:

@@ -1,6 +1,6 @@
 """LayerNorm backward at the Swin shapes (optionally with another library: GE_LIB=...): python tools/ubench/ln_time.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from gedepth_amd import hip
 if os.environ.get('GE_LIB'):
