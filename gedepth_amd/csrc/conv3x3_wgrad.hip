@@ -129,7 +129,12 @@ extern "C" int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, i
   const int tiles_x = (W + WG_TW - 1) / WG_TW, tiles_y = (H + WG_TH - 1) / WG_TH;
   const long total = (long)N * tiles_y * tiles_x;
   const int blocks_out = (Cin / 32) * ((Cout + 63) / 64);
-  long ksplit = (1024 + blocks_out - 1) / blocks_out;              // ~4 workgroups per CU in total
+  // K split: ONE resident round of workgroups (two per CU: 54 KB of LDS each), rounded DOWN.  Every workgroup does the same amount of
+  // work, so a grid that exceeds the resident slots by a few workgroups costs a whole extra round: the round-3 rule (~1024 workgroups,
+  // rounded up) launched 1026 for 576 -> 64 (18 output blocks x 57) and 1025 for 160 -> 64 (5 x 205) = three rounds where two would do.
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t p; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return GE_ERR_BAD_ARG; cus = p.multiProcessorCount; }
+  long ksplit = (2L * cus) / blocks_out;
   if (ksplit > total) ksplit = total;
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 65535 || (Cout + 63) / 64 > 65535) return GE_ERR_UNSUPPORTED;

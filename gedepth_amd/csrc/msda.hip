@@ -1119,7 +1119,7 @@ static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* qu
                          const float* attw, const void* d_out, float* d_value, float* d_loc, float* d_attw, void* workspace,
                          size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream, const MsdaEmit* em,
                          bool value_only = false) {
-  if (!value || !spatial_hw || !loc || !attw || !d_out || !d_value || (!em && !value_only && (!d_loc || !d_attw))) return GE_ERR_BAD_ARG;
+  if (!value || !spatial_hw || !loc || !attw || !d_out || (!d_value && !em) || (!em && !value_only && (!d_loc || !d_attw))) return GE_ERR_BAD_ARG;
   if (B < 0 || Nv <= 0 || Nq < 0 || nH <= 0 || P <= 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
@@ -1179,6 +1179,10 @@ static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* qu
   }
   GE_LAUNCH_CHECK();
   msda_mark(ev, 1, s);
+  if (!d_value) {                                           // raw-gradient half only: the caller takes d_value from ge_msda_bwd_value_raw
+    if (ev) { std::lock_guard<std::mutex> lk(g_msda_mu); g_msda_pending.push_back(MsdaStageRec{0, ev[0], ev[1]}); }
+    return GE_OK;
+  }
   const int nbins = pl.nbins;
   MsdaWs ws;
   msda_ws_layout(nbins, seg_ints, pl.max_entries, (char*)workspace, &ws);
@@ -1513,8 +1517,9 @@ extern "C" int ge_msda_fwd_raw(const void* value, const int* spatial_hw, const i
   return msda_fwd_win_raw_launch(value, lv, query_hw, n_qseg, rw, out, B, Nv, Nq, nH, L, P, dtype, ge_stream(stream));
 }
 
-// Backward to the raw projection outputs: d_value (fp32, zero-filled by the caller), d_off_raw / d_logit_raw (storage type, fully
-// written) and, if d_ref != NULL, d_ref (B*Nq, L, 2) fp32.  Needs the workspace of ge_msda_bwd_workspace and a geometry for which
+// Backward to the raw projection outputs: d_value (fp32, zero-filled by the caller; NULL = skip the d_value scatter, e.g. when the
+// caller takes it from ge_msda_bwd_value_raw), d_off_raw / d_logit_raw (storage type, fully written) and, if d_ref != NULL, d_ref
+// (B*Nq, L, 2) fp32.  Needs the workspace of ge_msda_bwd_workspace and a geometry for which
 // ge_msda_raw_supported() is 1.
 extern "C" int ge_msda_bwd_raw(const void* value, const int* spatial_hw, const int* query_hw, int n_qseg, const float* loc, const float* attw,
                                const void* d_out, float* d_value, void* d_off_raw, long off_ld, void* d_logit_raw, long logit_ld, float* d_ref,

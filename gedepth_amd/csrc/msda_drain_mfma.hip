@@ -34,14 +34,20 @@ __device__ __forceinline__ bf16_t md_bf(float f) { return __builtin_bit_cast(bf1
 // REC8: 8-byte records (bf16 weight, 8-bit fractions: the coefficients are rounded to bf16 in the image anyway; a fraction is taken at
 // the centre of its 1/256 step, so a coefficient moves by <= 2^-9 of the point's weight) — half the record bytes of fill and drain.
 template <bool REC8> struct MdRec;
+// Records are read exactly once: loaded with the non-temporal hint so that the 2.3 GB stream does not push the gradient rows (which the
+// range-grouped work order keeps re-using, msda_order_k) out of the XCD's L2.
+typedef int md_i32x4 __attribute__((ext_vector_type(4)));
+typedef int md_i32x2 __attribute__((ext_vector_type(2)));
 template <> struct MdRec<false> {
   typedef int4 T;
+  static __device__ __forceinline__ T load(const T* p) { const md_i32x4 v = __builtin_nontemporal_load((const md_i32x4*)p); return make_int4(v.x, v.y, v.z, v.w); }
   static __device__ __forceinline__ T pad(int key) { return make_int4(key, 0, 0, 0); }
   static __device__ __forceinline__ int key(const T& e) { return e.x; }
   static __device__ __forceinline__ void coef(const T& e, float& w, float& ax, float& ay) { w = __int_as_float(e.y); ax = __int_as_float(e.z); ay = __int_as_float(e.w); }
 };
 template <> struct MdRec<true> {
   typedef int2 T;
+  static __device__ __forceinline__ T load(const T* p) { const md_i32x2 v = __builtin_nontemporal_load((const md_i32x2*)p); return make_int2(v.x, v.y); }
   static __device__ __forceinline__ T pad(int key) { return make_int2(key, 0); }
   static __device__ __forceinline__ int key(const T& e) { return e.x; }
   static __device__ __forceinline__ void coef(const T& e, float& w, float& ax, float& ay) {
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins
     rec_t E0, E1, E2;
     // a record slot past the end of the chunk: zero weight, the query of the chunk's first record (a row that exists)
     const rec_t padrec = MdRec<REC8>::pad(MdRec<REC8>::key(ent[0]));
-#define MD_LOAD(DST, BLK) { DST = padrec; if ((BLK) * MD_BLK + lane < n) DST = ent[(BLK) * MD_BLK + lane]; }
+#define MD_LOAD(DST, BLK) { DST = padrec; if ((BLK) * MD_BLK + lane < n) DST = MdRec<REC8>::load(ent + (BLK) * MD_BLK + lane); }
 #define MD_GATHER(EE)                                                                          \
   _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                              \
     const int q = __shfl(MdRec<REC8>::key(EE) >> 7, i * 8 + row8, 64);                                       \

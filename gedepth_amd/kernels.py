@@ -311,7 +311,14 @@ class _MSDeformAttnRaw(torch.autograd.Function):
             hip.ptr(value, name='value'), ctypes.cast(arr, ctypes.c_void_p), qarr, nq, base, ld, base + n_off * es, ld, ref.data_ptr(),
             ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(loc), hip.ptr(attw), hip.ptr(out), B, Nv, Nq, nH, L, P,
             hip.dtype_code(value), hip.stream()), 'ge_msda_fwd_raw'))
-        ctx.save_for_backward(value, loc, attw)
+        # bf16: d_value is binned straight from the raw projections with 8-byte records (ge_msda_bwd_value_raw: half the record bytes
+        # of the fp32 loc / attw path in fill and drain), so the backward needs them too
+        ctx.value_from_raw = (value.dtype == torch.bfloat16 and L == 4 and P == 8 and 'msda_value_raw' not in DISABLED
+                              and max(max(hw) for hw in spatial_shapes) <= 8191)
+        if ctx.value_from_raw:
+            ctx.save_for_backward(value, loc, attw, raw, ref)
+        else:
+            ctx.save_for_backward(value, loc, attw)
         ctx.meta = (tuple(tuple(int(v) for v in hw) for hw in spatial_shapes), tuple(tuple(int(v) for v in hw) for hw in query_shapes),
                     nH, L, P, ld, raw.dtype)
         ctx.last_loc = loc
@@ -319,7 +326,8 @@ class _MSDeformAttnRaw(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        value, loc, attw = ctx.saved_tensors
+        value, loc, attw = ctx.saved_tensors[:3]
+        split = ctx.value_from_raw
         shapes, qshapes, nH, L, P, ld, dtype = ctx.meta
         B, Nv, _, D = value.shape
         Nq = loc.shape[1]
@@ -339,12 +347,23 @@ class _MSDeformAttnRaw(torch.autograd.Function):
         if PROFILER.on:
             lw_b = value.numel() * _es(value) + (loc.numel() + attw.numel()) * 4 + d_raw.numel() * es + d_out.numel() * _es(d_out)
             la_b = (loc.numel() + attw.numel()) * 4
-            PROFILER.add_stage_bytes((lw_b, la_b, 0, la_b, d_out.numel() * _es(d_out) + d_value.numel() * 4))
+            PROFILER.add_stage_bytes((lw_b, 0, 0, 0, 0) if split else (lw_b, la_b, 0, la_b, d_out.numel() * _es(d_out) + d_value.numel() * 4))
         nbytes = (value.numel() * _es(value) + (loc.numel() + attw.numel()) * 4 + d_raw.numel() * es + d_out.numel() * _es(d_out)
-                  + d_value.numel() * 4)
-        PROFILER.run(f'msda_bwd_raw[B{B} Nq{Nq} Nv{Nv} {_tag(value)}]', nbytes, lambda: hip.check(lib.ge_msda_bwd_raw(
-            hip.ptr(value), shapes_p, qarr, nq, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out), hip.ptr(d_value), base, ld, base + n_off * es, ld,
-            hip.ptr(d_ref), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()), 'ge_msda_bwd_raw'))
+                  + (0 if split else d_value.numel() * 4))
+        PROFILER.run(f'msda_bwd_raw[B{B} Nq{Nq} Nv{Nv} {_tag(value)}{" lw" if split else ""}]', nbytes, lambda: hip.check(lib.ge_msda_bwd_raw(
+            hip.ptr(value), shapes_p, qarr, nq, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out), None if split else hip.ptr(d_value), base, ld,
+            base + n_off * es, ld, hip.ptr(d_ref), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
+            'ge_msda_bwd_raw'))
+        if split:
+            raw, ref = ctx.saved_tensors[3:]
+            rbase = hip.ptr(raw)
+            if PROFILER.on:
+                PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, d_out.numel() * 2 + d_value.numel() * 4))
+            PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}]', B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
+                         lambda: hip.check(lib.ge_msda_bwd_value_raw(
+                             shapes_p, rbase, ld, rbase + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+                             hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value),
+                             hip.stream()), 'ge_msda_bwd_value_raw'))
         return d_value.to(value.dtype), d_raw, d_ref, None, None, None, None, None
 
 

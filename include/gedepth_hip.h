@@ -161,7 +161,8 @@ int ge_msda_prep_bwd(const float* d_loc, const float* d_attw, const float* attw,
  *   off_raw   (B*Nq rows of off_ld elements; columns (head, level, point, xy)), logit_raw (rows of logit_ld; columns (head,
  *             level, point)), storage type `dtype`; ref (B, Nq, L, 2) f32 with ELEMENT strides ref_sb / ref_sq / ref_sl (0 = broadcast)
  *   loc, attw (B,Nq,nH,L,P[,2]) f32: WRITTEN by the forward, read by the backward (what ge_msda_prep_fwd would have produced)
- *   d_off_raw / d_logit_raw: same layout and type as off_raw / logit_raw, fully written; d_ref (B*Nq, L, 2) f32 or NULL.
+ *   d_off_raw / d_logit_raw: same layout and type as off_raw / logit_raw, fully written; d_ref (B*Nq, L, 2) f32 or NULL;
+ *   d_value NULL in ge_msda_bwd_raw = skip the d_value scatter (the caller takes it from ge_msda_bwd_value_raw: 8-byte records).
  * ge_msda_raw_supported() = 1 when the fused kernels apply (L == 4, P == 8, a query grid, default kernel-selection mode);
  * ge_msda_fwd_raw otherwise runs the two-pass composition itself, ge_msda_bwd_raw returns GE_ERR_UNSUPPORTED. */
 int ge_msda_raw_supported(const int* spatial_hw, const int* query_hw, int n_qseg, int B, int Nv, int Nq, int nH, int L, int P);
