@@ -876,13 +876,13 @@ class _Conv3x3(torch.autograd.Function):
                 dx = _conv3x3_launch(dy, wt, None, 0, 1.0)
             if ctx.needs_input_grad[1]:
                 Ci = x.shape[1]
-                # measured against MIOpen's wrw kernels (tools/ubench/conv_time.py, CONV_SWINL=1 for the 2-image Swin-L shapes): the MFMA weight
-                # gradient wins where the pixel count is large (176 x 560 x 8: 901 vs 1328 us for 576 -> 64); at 8 images it ties at
-                # 88 x 280 and loses on the coarse levels (few pixel tiles per K split, many output blocks: atomics + zero fill), but
-                # MIOpen's kernels get their parallelism from the batch: at 2 images per GPU (configs #3) ours wins 11 of 14 layers by
-                # 1.1 - 1.9x (576 -> 64 @176x560: 268 vs 474 us) — all but the two smallest problems and the 11 x 35 maps
-                px, gflop = N * H * W, 18e-9 * N * H * W * Ci * Co
-                if 'conv3x3_wgrad' not in DISABLED and w_dtype == _f32 and (px >= 400000 or (N <= 4 and px >= 2000 and gflop >= 25.0)):
+                # measured against MIOpen's wrw kernels (tools/ubench/conv_time.py, CONV_SWINL=1 for the 2-image Swin-L shapes;
+                # profiles/r4_conv_time.txt).  Round 4 (K split = one resident round, staging indices hoisted out of the tile loop, operand
+                # reads software-pipelined): 576 -> 64 @176x560 x 8: 630 vs 1322 us, 608 -> 96 @88x280: 302 vs 446, 704 -> 192 @44x140: 165 vs
+                # 245, 1152 -> 384 @22x70: 167 vs 190; it still loses on the 11 x 35 maps (1280 -> 768: 151 vs 118: 32 pixel tiles for 480
+                # output blocks).  At 2 images per GPU (config #3) MIOpen's kernels lose their batch parallelism: ours wins 15 of 17 layers
+                # by 1.1 - 3.6x (576 -> 64 @176x560: 162 vs 489 us)
+                if 'conv3x3_wgrad' not in DISABLED and w_dtype == _f32 and (px >= 10000 or (N <= 4 and px >= 2000 and gflop >= 25.0)):
                     # MFMA weight gradient, fp32 accumulation straight into an (O, H, W, I) tensor = a channels-last (O, I, 3, 3) gradient
                     dw_ohwi = torch.zeros(Co, 3, 3, Ci, device=dy.device, dtype=_f32)
                     PROFILER.run(f'conv3x3_wgrad[{N}x{Ci}->{Co} {H}x{W}]', (x.numel() + dy.numel()) * 2 + dw_ohwi.numel() * 4, lambda: hip.check(

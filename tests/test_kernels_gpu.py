@@ -1671,7 +1671,7 @@ def test_conv3x3_mfma_vs_conv2d(dev, geom, act, variant, monkeypatch):
     kernels.PROFILER.disable()
     names = [r['name'] for r in kernels.PROFILER.summary()]
     assert sum(n.startswith('conv3x3[') for n in names) == 2                                      # forward and data gradient on the MFMA kernel
-    # the MFMA weight gradient is used from 4e5 pixels (where it beats MIOpen); checked here directly at every geometry
+    # the MFMA weight gradient is used from 1e4 pixels (where it beats MIOpen); checked here directly at every geometry
     dw = torch.zeros(Co, 3, 3, Ci, device=dev)
     from gedepth_amd import hip
     xb, gb = xg.detach(), go.to(dev).contiguous(memory_format=torch.channels_last)
