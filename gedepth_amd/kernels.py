@@ -882,6 +882,7 @@ class _Conv3x3(torch.autograd.Function):
                 # 245, 1152 -> 384 @22x70: 167 vs 190; it still loses on the 11 x 35 maps (1280 -> 768: 151 vs 118: 32 pixel tiles for 480
                 # output blocks).  At 2 images per GPU (config #3) MIOpen's kernels lose their batch parallelism: ours wins 15 of 17 layers
                 # by 1.1 - 3.6x (576 -> 64 @176x560: 162 vs 489 us)
+                px, gflop = N * H * W, 18e-9 * N * H * W * Ci * Co
                 if 'conv3x3_wgrad' not in DISABLED and w_dtype == _f32 and (px >= 10000 or (N <= 4 and px >= 2000 and gflop >= 25.0)):
                     # MFMA weight gradient, fp32 accumulation straight into an (O, H, W, I) tensor = a channels-last (O, I, 3, 3) gradient
                     dw_ohwi = torch.zeros(Co, 3, 3, Ci, device=dy.device, dtype=_f32)
