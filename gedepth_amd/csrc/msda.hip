@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256) msda_drain_k(MsdaLevels lv, MsdaBins bins
       ++probe;
     }
     if (item < 0) break;
-    item = ws.order[item];                                // work order -> chunk id (msda_order_k)
+    if (ws.order) item = ws.order[item];                  // work order -> chunk id (msda_order_k, mode bit 6)
     int lo = 0, hi = nbins;                               // largest bin with chunk_first[bin] <= item
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_first[mid] <= item) lo = mid; else hi = mid; }
     const int bin = lo;
@@ -1003,8 +1003,9 @@ static int msda_bins(const MsdaLevels& lv, int L, MsdaBins& bins) {
 // owner-lane tap arithmetic in the window kernels, bit 3 = head-major work order in the streaming kernels; the
 // streaming kernels serve everything else.  A process-wide knob for A/B timing and for the tests that compare the two.
 // bit 4 = bf16 d_value drain on the matrix cores (msda_drain_mfma.hip), bit 5 = its B operand through ds_read_b64_tr_b16,
-// bit 6 = drain work order grouped by query range (msda_order_k) instead of bin order.
-static int g_msda_mode = 13 | 16 | 32 | 64;   // window forward + owner-lane taps + head-major streaming d_loc/d_attw + MFMA drain + range-grouped drain order (measured best)
+// bit 6 = drain work order grouped by query range (msda_order_k) instead of bin order: opt-in — it cuts the drain's re-fetch traffic by
+// 28 % but the ordering pass costs what the drain gains (profiles/r4_ab_drain_order.txt).
+static int g_msda_mode = 13 | 16 | 32;   // window forward + owner-lane taps + head-major streaming d_loc/d_attw + MFMA drain (measured best); bit 6 (range-grouped drain order) is opt-in
 extern "C" int ge_msda_mode(int mode) {
   const int old = g_msda_mode;
   if (mode >= 0) g_msda_mode = mode & 127;
@@ -1197,8 +1198,10 @@ static int msda_bwd_impl(const void* value, const int* spatial_hw, const int* qu
   GE_LAUNCH_CHECK();
   msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.ntiles, pl.R, nbins);
   GE_LAUNCH_CHECK();
-  msda_order_k<<<(unsigned)(B * nH), 1024, 0, s>>>(ws, pl.ntiles, pl.R, (g_msda_mode & 64) != 0);
-  GE_LAUNCH_CHECK();
+  if (g_msda_mode & 64) {
+    msda_order_k<<<(unsigned)(B * nH), 1024, 0, s>>>(ws, pl.ntiles, pl.R, 1);
+    GE_LAUNCH_CHECK();
+  } else ws.order = nullptr;                               // bin order
   msda_mark(ev, 3, s);
   msda_hist_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, loc, attw, ws, Nq, nH, L, P, pl.R, B);
   GE_LAUNCH_CHECK();
@@ -1277,8 +1280,10 @@ extern "C" int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw,
   GE_LAUNCH_CHECK();
   msda_segscan_k<<<(unsigned)((nbins + 255) / 256), 256, 0, s>>>(ws, pl.ntiles, pl.R, nbins);
   GE_LAUNCH_CHECK();
-  msda_order_k<<<(unsigned)(B * nH), 1024, 0, s>>>(ws, pl.ntiles, pl.R, (g_msda_mode & 64) != 0);
-  GE_LAUNCH_CHECK();
+  if (g_msda_mode & 64) {
+    msda_order_k<<<(unsigned)(B * nH), 1024, 0, s>>>(ws, pl.ntiles, pl.R, 1);
+    GE_LAUNCH_CHECK();
+  } else ws.order = nullptr;                               // bin order
   msda_mark(ev, 3, s);
   msda_hist_raw_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B);
   GE_LAUNCH_CHECK();
@@ -1462,7 +1467,11 @@ extern "C" int ge_msda_prep_bwd(const float* d_loc, const float* d_attw, const f
 
 // ============================================================================ fused prepare + sampling ("raw" entry points)
 // d_ref[b, q, l, :] = sum_{h, p} d_loc[b, q, h, l, p, :] from the emitted d_off_raw = d_loc / (W_l, H_l) (the heads of a query are
-// spread over workgroups in the head-major d_loc / d_attw kernel, so the sum is a small pass of its own: one thread per (row, level))
+// spread over workgroups in the head-major d_loc / d_attw kernel, so the sum is a small pass of its own: one thread per (row, level)).
+// Parity note: with bf16 storage d_off_raw is already rounded to bf16 when it is read back here, so d_ref carries one bf16 rounding per
+// (head, point) term (2^-9 relative each, nH * P = 64 terms per reference point and level) that the composed path (ge_msda_prep_bwd, which
+// sums the fp32 d_loc) does not have; fp32 storage is exact either way.  The consumer is the gradient of the `reference_points` Linear of
+// the cross-attention (hahi.py:294-302), whose other operand is bf16 as well; tests/test_kernels_gpu.py bounds it at the bf16 tolerance.
 template <typename T>
 __global__ void __launch_bounds__(256) msda_dref_k(const T* __restrict__ d_off, long off_ld, MsdaLevels lv, float* __restrict__ d_ref, long rows,
                                                    int nH) {

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) msda_drain_mfma_k(MsdaLevels lv, MsdaBins
       ++probe;
     }
     if (item < 0) break;
-    item = ws.order[item];                                // work order -> chunk id (msda_order_k, msda.hip: chunks grouped by query range)
+    if (ws.order) item = ws.order[item];                  // work order -> chunk id (msda_order_k, msda.hip: chunks grouped by query range; mode bit 6)
     int lo = 0, hi = nbins;                               // largest bin with chunk_first[bin] <= item
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_first[mid] <= item) lo = mid; else hi = mid; }
     const int bin = lo;

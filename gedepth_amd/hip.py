@@ -82,6 +82,7 @@ SIGNATURES = {
     'ge_upsum_nhwc_fwd': (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_conv3x3_nhwc_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'ge_conv3x3_nhwc_wgrad': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_conv1x1_nhwc_wgrad': (_i, [_vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     'ge_conv3x3_c1_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_conv3x3_c1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_gemm_nt': (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
@@ -122,7 +123,7 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = handle
         if os.environ.get('GE_MSDA_MODE'):           # kernel-selection knob of the deformable attention (kernels.msda_mode), e.g.
-            handle.ge_msda_mode(int(os.environ['GE_MSDA_MODE']))      # 124 = default without the bf16-tap-weight window forward
+            handle.ge_msda_mode(int(os.environ['GE_MSDA_MODE']))      # 60 = default without the bf16-tap-weight window forward
     return _lib
 
 

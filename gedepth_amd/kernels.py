@@ -163,8 +163,8 @@ def _query_grid(query_shapes, Nq):
 def msda_mode(mode=-1):
     """Kernel-selection knob of the deformable-attention ops; returns the previous mode.  Bits: 0 window (LDS-staged) forward,
     1 window d_loc / d_attw, 2 owner-lane tap arithmetic in the window kernels, 3 head-major work order of the streaming kernels,
-    4 bf16 d_value drain on MFMA, 5 its operand reads through ds_read_b64_tr_b16, 6 drain work order grouped by query range.  Default 125;
-    ``GE_MSDA_MODE`` in the environment sets it at library load (e.g. 124: streaming forward with exact fp32 tap weights for accuracy-parity runs in bf16)."""
+    4 bf16 d_value drain on MFMA, 5 its operand reads through ds_read_b64_tr_b16, 6 drain work order grouped by query range (opt-in: less re-fetch traffic, same time).
+    Default 61; ``GE_MSDA_MODE`` in the environment sets it at library load (e.g. 60: streaming forward with exact fp32 tap weights for accuracy-parity runs in bf16)."""
     return int(hip.lib().ge_msda_mode(int(mode)))
 
 
@@ -937,10 +937,40 @@ class _ConvLib(torch.autograd.Function):
     def backward(ctx, dy):
         xc, wc = ctx.saved_tensors
         stride, padding, dilation, groups, x_dtype, w_dtype = ctx.meta
+        dy = dy.to(wc.dtype)
+        own_dw = ctx.needs_input_grad[1] and conv1x1_wgrad_ok(xc, dy, wc, stride, padding, dilation, groups)
         with torch.autocast('cuda', enabled=False):
-            dx, dw, _ = torch.ops.aten.convolution_backward(dy.to(wc.dtype), xc, wc, None, stride, padding, dilation, False, (0, 0), groups,
-                                                            (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False))
+            dx, dw, _ = torch.ops.aten.convolution_backward(dy, xc, wc, None, stride, padding, dilation, False, (0, 0), groups,
+                                                            (ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_dw, False))
+        if own_dw:
+            dw = conv1x1_wgrad(xc, dy).view(wc.shape)
         return (None if dx is None else dx.to(x_dtype)), (None if dw is None else dw.to(w_dtype)), None, None, None, None
+
+
+def conv1x1_wgrad_ok(x, dy, w, stride, padding, dilation, groups):
+    """The streaming MFMA weight gradient of a 1x1 convolution applies (csrc/conv1x1_wgrad.hip): bf16 channels-last maps, plain 1x1 / stride 1
+    geometry, channel counts the kernel tiles (Cin a multiple of 64 or 96, Cout of 32), enough rows to stream."""
+    if 'conv1x1_wgrad' in DISABLED or tuple(w.shape[2:]) != (1, 1) or groups != 1:
+        return False
+    if tuple(stride) != (1, 1) or tuple(padding) != (0, 0) or tuple(dilation) != (1, 1):
+        return False
+    Co, Ci = w.shape[:2]
+    if x.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16 or Co % 32 or (Ci % 64 and Ci % 96):
+        return False
+    return (x.is_cuda and _is_cl(x) and _is_cl(dy) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and x.shape[0] * x.shape[2] * x.shape[3] >= 2048)
+
+
+def conv1x1_wgrad(x, dy):
+    """dW (Cout, Cin) fp32 = sum over the N H W pixels of dy x^T for channels-last bf16 maps x (N, Cin, H, W), dy (N, Cout, H, W)."""
+    N, Ci, H, W = x.shape
+    Co = dy.shape[1]
+    M = N * H * W
+    dw = torch.zeros(Co, Ci, device=x.device, dtype=_f32)
+    PROFILER.run(f'conv1x1_wgrad[{N}x{Ci}->{Co} {H}x{W}]', (x.numel() + dy.numel()) * 2 + dw.numel() * 4, lambda: hip.check(
+        hip.lib().ge_conv1x1_nhwc_wgrad(_raw_ptr(x, 'x'), _raw_ptr(dy, 'dy'), hip.ptr(dw), M, Ci, Co, hip.GE_BF16, hip.stream()),
+        'ge_conv1x1_nhwc_wgrad'), flops=2 * M * Ci * Co)
+    return dw
 
 
 def conv_lib(conv, x):

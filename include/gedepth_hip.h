@@ -405,6 +405,10 @@ int ge_conv3x3_nhwc_fwd(const void* x, const void* w, const float* bias, void* y
  * sum over pixels of dy (N,H,W,Cout) x shifted x (N,H,W,Cin); both bf16 channels-last; the CALLER zero-fills dw (partial sums of the
  * K-split workgroups meet through fp32 atomics).  Cin % 32 == 0, Cout % 8 == 0. */
 int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int Cout, int dtype, void* stream);
+/* Weight gradient of a 1x1 convolution on channels-last bf16 maps (csrc/conv1x1_wgrad.hip; reference layers: the ConvModule(k = 1) blocks
+ * of necks/hahi.py:120-166): dw (Cout, Cin) fp32 += dy^T x over the M = N H W rows; x (M, Cin), dy (M, Cout) row-major; the CALLER zero-fills
+ * dw.  Cin % 64 == 0 or Cin % 96 == 0, Cout % 32 == 0, dtype GE_BF16. */
+int ge_conv1x1_nhwc_wgrad(const void* x, const void* dy, float* dw, long M, int Cin, int Cout, int dtype, void* stream);
 /* The same layer with ONE output channel (csrc/conv3x3_c1.hip): the depth regressor `conv_depth` (reference
  * depth/models/decode_heads/decode_head.py: nn.Conv2d(channels, 1, 3, padding=1)) and `convfinal` of the ground-attention neck
  * (necks/pemask_neck.py:36-42): a streaming reduction on the vector pipe (v_dot2c_f32_bf16), not a GEMM with N = 1.

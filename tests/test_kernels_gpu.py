@@ -327,13 +327,13 @@ def test_msda_window_kernels(dev, case, dtype):
     stream = run(0, qshapes)
     stream_hm = run(8, qshapes)                             # streaming kernels, head-major work order
     mix = run(13, qshapes)                                  # window forward, streaming head-major backward, VALU drain
-    bin_order = run(61, qshapes)                            # the same + bf16 d_value drain on MFMA (transposing LDS reads), chunks drained in bin order
-    default = run(125, qshapes)                             # the default: + drain work order grouped by query range (msda_order_k)
+    default = run(61, qshapes)                              # the default: the same + bf16 d_value drain on MFMA (transposing LDS reads), chunks drained in bin order
+    grouped = run(125, qshapes)                             # + drain work order grouped by query range (msda_order_k, opt-in)
     mfma_plain = run(29, qshapes)                           # MFMA drain with plain 16-bit LDS reads for the B operand
     names = ('out', 'd value', 'd loc', 'd attw')
     # same arithmetic per (query, head): the decompositions agree to the order of the 8-lane / 16-lane reductions
     for w, tag in ((win, 'window'), (win_plain, 'window (per-lane taps)'), (stream_hm, 'streaming head-major'), (mix, 'mode 13'),
-                   (bin_order, 'mode 61'), (default, 'default mode 125'), (mfma_plain, 'mode 29')):
+                   (default, 'default mode 61'), (grouped, 'mode 125'), (mfma_plain, 'mode 29')):
         for a, b, n in zip(w, stream, names):
             if dtype == 'f32':
                 close_scaled(a, b, rel=2e-5, what=f'{tag} vs streaming: {n}')
@@ -498,8 +498,8 @@ def test_msda_raw_fused_prepare_and_sampling(dev, dtype, case):
     arr = (ctypes.c_int * 8)(*[x for hw in shapes for x in hw])
     qa = (ctypes.c_int * (2 * len(qshapes)))(*[x for hw in qshapes for x in hw])
     sup = hip.lib().ge_msda_raw_supported(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(qa, ctypes.c_void_p), len(qshapes), B, nv, nq, nH, L, P)
-    assert sup == 1                                            # the fused kernels are what `run(125)` exercises
-    fused = run(125)
+    assert sup == 1                                            # the fused kernels are what `run(61)` exercises
+    fused = run(61)
     composed = run(60)                                         # mode without the window forward: prepare pass + streaming kernels
     n_off = nH * L * P * 2
     names = ('out', 'd value', 'd raw', 'd ref')
@@ -1630,6 +1630,53 @@ def test_upsum_matches_pe_trunk_composition(dev, dtype):
     close_scaled(fg.grad.float(), f64.grad, rel=tol, what='d fine')
     for a, b, s in zip(cg, c64, sizes):
         close_scaled(a.grad.float(), b.grad, rel=tol, what=f'd coarse {s}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('geom', [(2, 64, 512, 16, 40), (1, 96, 512, 13, 37), (2, 192, 512, 9, 33), (1, 768, 768, 11, 35), (1, 64, 64, 8, 32),
+                                  (1, 384, 512, 22, 70), (2, 96, 96, 44, 70), (1, 64, 544, 30, 33)])
+def test_conv1x1_wgrad_vs_float64(dev, geom):
+    """ge_conv1x1_nhwc_wgrad (csrc/conv1x1_wgrad.hip: dW = dY^T X streamed over the pixels, MFMA with transposing LDS reads, K split with an
+    fp32 atomic flush) against a float64 contraction of the same bf16-rounded operands: row counts that are not multiples of the 64-row
+    stage, one / several Cin chunks of 64 and of 96, Cout above 512 (two Cout chunks, the second partial), the HAHI shapes."""
+    from gedepth_amd import kernels
+    N, Ci, Co, H, W = geom
+    g = gen(31)
+    cl = torch.channels_last
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=cl)
+    dy = torch.randn(N, Co, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=cl)
+    w = torch.empty(Co, Ci, 1, 1, device=dev, dtype=torch.bfloat16)
+    assert kernels.conv1x1_wgrad_ok(x, dy, w, (1, 1), (0, 0), (1, 1), 1) == (N * H * W >= 2048)
+    dw = kernels.conv1x1_wgrad(x, dy)
+    ref = torch.einsum('nohw,nihw->oi', dy.double(), x.double())
+    close_scaled(dw, ref, rel=2e-5, what=f'conv1x1 wgrad {geom}')
+
+
+@pytest.mark.gpu
+def test_conv_module_1x1_uses_own_wgrad_and_matches_library(dev, monkeypatch):
+    """A ConvModule(k = 1)-style convolution under bf16 autocast through kernels.conv_lib: the weight gradient comes from
+    ge_conv1x1_nhwc_wgrad (profiler record) and equals the library's (GE_DISABLE=conv1x1_wgrad) to fp32-accumulation accuracy; dx unchanged."""
+    from gedepth_amd import kernels
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(64, 512, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
+    x0 = torch.randn(2, 64, 40, 56, device=dev).contiguous(memory_format=torch.channels_last)
+    go = torch.randn(2, 512, 40, 56, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        conv.weight.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = kernels.conv_lib(conv, x)
+        y.backward(go)
+        return y.float(), x.grad.float(), conv.weight.grad.float().clone()
+    kernels.PROFILER.enable()
+    y1, dx1, dw1 = run()
+    kernels.PROFILER.disable()
+    assert any(r['name'].startswith('conv1x1_wgrad') for r in kernels.PROFILER.summary())
+    monkeypatch.setattr(kernels, 'DISABLED', kernels.DISABLED | {'conv1x1_wgrad'})
+    y2, dx2, dw2 = run()
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    close_scaled(dw1, dw2, rel=1e-2, what='1x1 weight gradient: own (fp32 accumulation) vs library (bf16 result)')
 
 
 @pytest.mark.gpu
