@@ -90,6 +90,7 @@ def _es(t):
 # A/B switch for the fused passes added in round 3: GE_DISABLE=upcat,upsum,bias_gelu,msda_raw makes the named entry points take their
 # two-pass composition (still HIP kernels / library calls: a measurement aid for same-box comparisons, not a fall-back)
 DISABLED = {t for t in os.environ.get('GE_DISABLE', '').split(',') if t}
+ENABLED = {t for t in os.environ.get('GE_ENABLE', '').split(',') if t}        # opt-in paths that measured slower than their alternative
 
 
 def _tag(t):
@@ -949,8 +950,11 @@ class _ConvLib(torch.autograd.Function):
 
 def conv1x1_wgrad_ok(x, dy, w, stride, padding, dilation, groups):
     """The streaming MFMA weight gradient of a 1x1 convolution applies (csrc/conv1x1_wgrad.hip): bf16 channels-last maps, plain 1x1 / stride 1
-    geometry, channel counts the kernel tiles (Cin a multiple of 64 or 96, Cout of 32), enough rows to stream."""
-    if 'conv1x1_wgrad' in DISABLED or tuple(w.shape[2:]) != (1, 1) or groups != 1:
+    geometry, channel counts the kernel tiles (Cin a multiple of 64 or 96, Cout of 32), enough rows to stream.
+    OPT-IN (``GE_ENABLE=conv1x1_wgrad``): measured on MI355X it ties the library on the one large problem (64 -> 512 @176x560 x 8: 193 vs 180 us,
+    both at the HBM rate) and loses on the small ones (zero fill + atomic flush + one round of 256 workgroups for 25 - 60 us of work): 687 vs
+    498 us over the ten 1x1 layers, step 50.03 vs 49.77 ms same-session (profiles/r4_conv1x1_wgrad_time.txt) — so the default stays MIOpen / CK."""
+    if 'conv1x1_wgrad' not in ENABLED or 'conv1x1_wgrad' in DISABLED or tuple(w.shape[2:]) != (1, 1) or groups != 1:
         return False
     if tuple(stride) != (1, 1) or tuple(padding) != (0, 0) or tuple(dilation) != (1, 1):
         return False

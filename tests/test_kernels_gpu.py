@@ -1635,7 +1635,7 @@ def test_upsum_matches_pe_trunk_composition(dev, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize('geom', [(2, 64, 512, 16, 40), (1, 96, 512, 13, 37), (2, 192, 512, 9, 33), (1, 768, 768, 11, 35), (1, 64, 64, 8, 32),
                                   (1, 384, 512, 22, 70), (2, 96, 96, 44, 70), (1, 64, 544, 30, 33)])
-def test_conv1x1_wgrad_vs_float64(dev, geom):
+def test_conv1x1_wgrad_vs_float64(dev, geom, monkeypatch):
     """ge_conv1x1_nhwc_wgrad (csrc/conv1x1_wgrad.hip: dW = dY^T X streamed over the pixels, MFMA with transposing LDS reads, K split with an
     fp32 atomic flush) against a float64 contraction of the same bf16-rounded operands: row counts that are not multiples of the 64-row
     stage, one / several Cin chunks of 64 and of 96, Cout above 512 (two Cout chunks, the second partial), the HAHI shapes."""
@@ -1646,6 +1646,7 @@ def test_conv1x1_wgrad_vs_float64(dev, geom):
     x = torch.randn(N, Ci, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=cl)
     dy = torch.randn(N, Co, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=cl)
     w = torch.empty(Co, Ci, 1, 1, device=dev, dtype=torch.bfloat16)
+    monkeypatch.setattr(kernels, 'ENABLED', kernels.ENABLED | {'conv1x1_wgrad'})          # opt-in path (measured slower than the library: kernels.conv1x1_wgrad_ok)
     assert kernels.conv1x1_wgrad_ok(x, dy, w, (1, 1), (0, 0), (1, 1), 1) == (N * H * W >= 2048)
     dw = kernels.conv1x1_wgrad(x, dy)
     ref = torch.einsum('nohw,nihw->oi', dy.double(), x.double())
@@ -1653,9 +1654,9 @@ def test_conv1x1_wgrad_vs_float64(dev, geom):
 
 
 @pytest.mark.gpu
-def test_conv_module_1x1_uses_own_wgrad_and_matches_library(dev, monkeypatch):
-    """A ConvModule(k = 1)-style convolution under bf16 autocast through kernels.conv_lib: the weight gradient comes from
-    ge_conv1x1_nhwc_wgrad (profiler record) and equals the library's (GE_DISABLE=conv1x1_wgrad) to fp32-accumulation accuracy; dx unchanged."""
+def test_conv_module_1x1_opt_in_wgrad_matches_library(dev, monkeypatch):
+    """A ConvModule(k = 1)-style convolution under bf16 autocast through kernels.conv_lib with the opt-in GE_ENABLE=conv1x1_wgrad: the weight
+    gradient comes from ge_conv1x1_nhwc_wgrad (profiler record) and equals the library's (the default) to fp32-accumulation accuracy; dx unchanged."""
     from gedepth_amd import kernels
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(64, 512, 1, bias=False).to(dev).to(memory_format=torch.channels_last)
@@ -1669,11 +1670,12 @@ def test_conv_module_1x1_uses_own_wgrad_and_matches_library(dev, monkeypatch):
             y = kernels.conv_lib(conv, x)
         y.backward(go)
         return y.float(), x.grad.float(), conv.weight.grad.float().clone()
+    monkeypatch.setattr(kernels, 'ENABLED', kernels.ENABLED | {'conv1x1_wgrad'})
     kernels.PROFILER.enable()
     y1, dx1, dw1 = run()
     kernels.PROFILER.disable()
     assert any(r['name'].startswith('conv1x1_wgrad') for r in kernels.PROFILER.summary())
-    monkeypatch.setattr(kernels, 'DISABLED', kernels.DISABLED | {'conv1x1_wgrad'})
+    monkeypatch.setattr(kernels, 'ENABLED', kernels.ENABLED - {'conv1x1_wgrad'})
     y2, dx2, dw2 = run()
     assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
     close_scaled(dw1, dw2, rel=1e-2, what='1x1 weight gradient: own (fp32 accumulation) vs library (bf16 result)')
