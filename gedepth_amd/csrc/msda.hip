@@ -668,28 +668,52 @@ __device__ __forceinline__ void msda_wave_scan(long& vo, int& vk, int lane) {   
   }
 }
 __global__ void __launch_bounds__(1024) msda_scan_k(MsdaWs ws, int nbins) {
+  // EIGHT bins per lane and step (two 16-byte loads; local prefix, then the wave scan over the lane totals): the loop is a chain of dependent
+  // global round trips, and with one bin per lane a 65 k-bin scan took 128 of them = 86 us per launch (rocprofv3, round 4)
   __shared__ long w_off[16];
   __shared__ int w_chk[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int seg = ((nbins + 15) / 16 + 63) / 64 * 64;
+  const int seg = ((nbins + 15) / 16 + 511) / 512 * 512;
   const int lo = wv * seg, hi = min(nbins, lo + seg);
+  auto load8 = [&](int i0, int* c) {
+    if (i0 + 8 <= hi) {
+      const int4 a = *(const int4*)(ws.cnt + i0), b = *(const int4*)(ws.cnt + i0 + 4);
+      c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) c[e] = i0 + e < hi ? ws.cnt[i0 + e] : 0;
+    }
+  };
   long to = 0; int tk = 0;
-  for (int i = lo + lane; i < hi; i += 64) { const int c = ws.cnt[i]; to += c; tk += (c + MSDA_CHUNK - 1) / MSDA_CHUNK; }
+  for (int base = lo; base < hi; base += 512) {
+    int c[8];
+    load8(base + lane * 8, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { to += c[e]; tk += (c[e] + MSDA_CHUNK - 1) / MSDA_CHUNK; }
+  }
 #pragma unroll
   for (int d = 32; d; d >>= 1) { to += __shfl_xor(to, d, 64); tk += __shfl_xor(tk, d, 64); }
   if (lane == 0) { w_off[wv] = to; w_chk[wv] = tk; }
   __syncthreads();
   long run_o = 0; int run_k = 0;
   for (int w = 0; w < wv; ++w) { run_o += w_off[w]; run_k += w_chk[w]; }
-  for (int base = lo; base < hi; base += 64) {
-    const int i = base + lane;
-    const int c = i < hi ? ws.cnt[i] : 0;
-    const int k = (c + MSDA_CHUNK - 1) / MSDA_CHUNK;
-    long vo = c; int vk = k;
-    msda_wave_scan(vo, vk, lane);
-    if (i < hi) { ws.offset[i] = run_o + vo - c; ws.chunk_first[i] = run_k + vk - k; }
-    run_o += __shfl(vo, 63, 64);
-    run_k += __shfl(vk, 63, 64);
+  for (int base = lo; base < hi; base += 512) {
+    const int i0 = base + lane * 8;
+    int c[8], kc[8];
+    load8(i0, c);
+    long vo = 0; int vk = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kc[e] = (c[e] + MSDA_CHUNK - 1) / MSDA_CHUNK; vo += c[e]; vk += kc[e]; }
+    long so = vo; int sk = vk;
+    msda_wave_scan(so, sk, lane);
+    long o = run_o + so - vo; int k = run_k + sk - vk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (i0 + e < hi) { ws.offset[i0 + e] = o; ws.chunk_first[i0 + e] = k; }
+      o += c[e]; k += kc[e];
+    }
+    run_o += __shfl(so, 63, 64);
+    run_k += __shfl(sk, 63, 64);
   }
   if (threadIdx.x == 0) {
     int total = 0;
