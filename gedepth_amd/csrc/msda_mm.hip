@@ -47,7 +47,9 @@ typedef short mm_s16x2 __attribute__((ext_vector_type(2)));
 #define MM_STAGE (2 * MM_HALF)
 #define MM_IMG ((MM_CAP + 4) * 32)       // coefficient image, TRANSPOSED: [window row k][32 queries] bf16 (+ 4 dump rows), see the kernel
 #ifndef MM_WAVES
-#define MM_WAVES 2                       // occupancy target per SIMD (registers); LDS allows 160 KB / (image + stage) per CU
+#define MM_WAVES 2                       // occupancy target per SIMD (registers); LDS allows 160 KB / (image + stage) per CU.  Measured with 3
+                                         // (168 VGPRs: 28 / 56 spilled registers in forward / d_raw): forward 2.19 vs 2.20 ms, d_raw 3.29 vs 2.43 ms
+                                         // (tools/ubench/ab_mm_waves.sh, round 4): the third wave does not pay for its scratch traffic
 #endif
 #ifndef MM_DBUF
 #define MM_DBUF 0                        // 1: two stage buffers (the next chunk's LDS-DMA runs under this chunk's MFMAs); measured: the
