@@ -89,21 +89,31 @@ __global__ void __launch_bounds__(256, 2) conv3x3_nhwc_k(const bf16_t* __restric
   for (int c0 = 0; c0 < Cin; c0 += CV_KC) {
     const bool more = c0 + CV_KC < Cin;
     if (more) { CV_PREFETCH(c0 + CV_KC) }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, s = tap - 3 * r;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+    // 18 steps = 9 taps x 2 K groups of 16 channels; the four fragments of step it + 1 are read into the second register set BEFORE the four
+    // MFMAs of step it issue (round 4: left to the compiler, every group of MFMAs waited on fragment reads issued a moment earlier —
+    // s_waitcnt lgkmcnt(1) / (0) in the middle of each tap)
+    {
+      cv_bf16x8 A[2][2], B[2][2];
+      auto frags = [&](int set, int it) {
+        const int tap = it >> 1, ks = it & 1, r = tap / 3, s = tap - 3 * r;
         const int ao = a_base0 + (r * (CV_TW + 2) + s) * CV_PITCH + ks * 16;
-        const cv_bf16x8 A0 = *(const cv_bf16x8*)(in_tile + ao);
-        const cv_bf16x8 A1 = *(const cv_bf16x8*)(in_tile + ao + (CV_TW + 2) * CV_PITCH);
+        A[set][0] = *(const cv_bf16x8*)(in_tile + ao);
+        A[set][1] = *(const cv_bf16x8*)(in_tile + ao + (CV_TW + 2) * CV_PITCH);
         const int bo = b_base + tap * CV_NT * CV_PITCH + ks * 16;
-        const cv_bf16x8 B0 = *(const cv_bf16x8*)(w_tile + bo);
-        const cv_bf16x8 B1 = *(const cv_bf16x8*)(w_tile + bo + 32 * CV_PITCH);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[1][1], 0, 0, 0);
+        B[set][0] = *(const cv_bf16x8*)(w_tile + bo);
+        B[set][1] = *(const cv_bf16x8*)(w_tile + bo + 32 * CV_PITCH);
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int it = 0; it < 18; ++it) {
+        if (it < 17) frags((it + 1) & 1, it + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = it & 1;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], B[c][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], B[c][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], B[c][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], B[c][1], acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();                                           // every wave is done reading this chunk
