@@ -17,8 +17,9 @@
  *   - thread-safe, and re-entrant except for three process-wide measurement / selection knobs that live in the library (mutex-guarded):
  *     the kernel-selection mode of the deformable attention (ge_msda_mode: an A/B switch for tests and timing; kernels read it at
  *     launch), the opt-in per-kernel timing of the composite MSDA backward (ge_msda_bwd_timing*: off by default, records nothing and
- *     never synchronises when off), and two cached device properties (CU count, occupancy of the persistent MSDA kernels).  No
- *     entry point keeps state that changes its RESULTS between calls.
+ *     never synchronises when off), and cached device properties (CU count, occupancy of the persistent MSDA kernels); ge_conv3x3_nhwc_fwd
+ *     reads the environment variable GE_CONV3X3 (A/B switch between its two kernels, same results).  No entry point keeps state that
+ *     changes its RESULTS between calls.
  */
 #ifndef GEDEPTH_HIP_H
 #define GEDEPTH_HIP_H
@@ -35,7 +36,7 @@ enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
 
 /* Library / device identification: returns the ABI version (3: round 3 added the raw-projection deformable-attention entry points,
  * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline; 4: round 4 added the MFMA
- * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw) and the token GEMM ge_gemm_nt). */
+ * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw), the token GEMM ge_gemm_nt and ge_conv1x1_nhwc_wgrad). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
