@@ -35,7 +35,7 @@ def parse():
     ap.add_argument('--width', type=int, default=1120)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--allreduce-dtype', default='fp32', choices=['fp32', 'bf16'], help='gradient all-reduce wire format (N > 1)')
-    ap.add_argument('--bucket-mb', type=float, default=None, help='DDP bucket size in MiB (default 64)')
+    ap.add_argument('--bucket-mb', type=float, default=None, help='DDP bucket size in MiB (default 32)')
     ap.add_argument('--attn', default='auto', choices=['auto', 'fp8'],
                     help="window attention: 'fp8' = e4m3 MFMA forward contractions (BASELINE.json configs[4]); 'auto' = bf16 MFMA")
     ap.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'],

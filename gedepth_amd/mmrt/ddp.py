@@ -3,8 +3,9 @@
 Replaces ``MMDistributedDataParallel`` as used by depth/apis/train.py:59-67 (reference): one process per GPU,
 ``broadcast_buffers=False``, every parameter receives a gradient.  MI355X-first design:
   * gradients already live in one contiguous fp32 buffer (gedepth_amd/mmrt/optim.py: GradArena), so a bucket is
-    a *slice* of it — no flatten / unflatten copies, and buckets can be large (default 64 MiB: xGMI is
-    point-to-point, 7 links x ~153 GB/s per GPU, so fewer, larger collectives amortise per-call latency);
+    a *slice* of it — no flatten / unflatten copies, and buckets can be large (default 32 MiB: xGMI is
+    point-to-point, 7 links x ~153 GB/s per GPU, so few, large collectives amortise per-call latency; 64 MiB was the default until the
+    single-rank bucket trace showed its cost: profiles/r4_bench_ddp_forced_single_rank.json, see __init__);
   * buckets are filled from the end of the arena (decoder / neck parameters first, the order backward
     produces them) and launched strictly in sequence with ``async_op=True`` on RCCL's stream, overlapping the
     rest of backward; ``finish()`` waits once before the optimizer kernel;
@@ -25,11 +26,15 @@ class FlatDDP(nn.Module):
         """``grad_dtype=torch.bfloat16`` halves the bytes on xGMI (1.10 GB -> 0.55 GB per step for Swin-L): each
         bucket is rounded into a bf16 staging buffer, all-reduced (sum) and widened back into the fp32 arena with the 1/world
         scale; the default (None) reduces the fp32 arena slices in place.  ``bucket_mb`` / ``GE_DDP_BUCKET_MB`` size the
-        buckets (default 64 MiB: per-link bandwidth ~153 GB/s, so a 64 MiB ring step is ~0.1 ms per hop and latency-amortised)."""
+        buckets.  Default 32 MiB: per-link bandwidth ~153 GB/s, so a 32 MiB ring step is still latency-amortised (~50 us per hop), and the
+        exchange overlaps more of backward.  Measured on one rank with the collectives forced (Swin-T, 214 MB of gradients, backward ~35 ms
+        from the first gradient): with 64 MiB buckets the decoder-end bucket launched at 25.6 ms and the other TWO (139 MB, neck tail +
+        the whole backbone) at 34.7 / 34.9 ms — when backward is over, i.e. nothing left to hide them behind on N > 1 ranks; the backbone's
+        backward is short (~5 ms), so only smaller buckets let its stage-3 gradients (57 MB) leave before the last layer finishes."""
         super().__init__()
         self.module, self.arena, self.group, self.overlap = module, arena, process_group, overlap
         if bucket_mb is None:
-            bucket_mb = float(os.environ.get('GE_DDP_BUCKET_MB', 64))
+            bucket_mb = float(os.environ.get('GE_DDP_BUCKET_MB', 32))
         if grad_dtype is None and os.environ.get('GE_DDP_GRAD_DTYPE', '') in ('bf16', 'bfloat16'):
             grad_dtype = torch.bfloat16
         assert grad_dtype in (None, torch.float32, torch.bfloat16)
@@ -60,7 +65,7 @@ class FlatDDP(nn.Module):
                     self.bucket_of[m] = len(self.buckets) - 1
                 end, members = off, []
         # the arena starts with the patch-embed / stage-0 parameters: built from the end, the LAST bucket would be a sliver (< 1 MB for
-        # Swin-T at 64 MiB buckets) whose collective starts when backward is already over — a latency-bound all-reduce that nothing
+        # Swin-T at 64 MiB buckets, 19 MB at 32 MiB) whose collective starts when backward is already over — a latency-bound all-reduce that nothing
         # overlaps.  A tail below a quarter of the bucket size joins its neighbour (the slices are contiguous).
         if len(self.buckets) >= 2 and (self.buckets[-1][1] - self.buckets[-1][0]) * 4 < cap:
             (lo2, _, m2), (_, hi1, m1) = self.buckets.pop(), self.buckets.pop()
@@ -71,6 +76,15 @@ class FlatDDP(nn.Module):
         self._works = []
         self._next = 0
         self._hooks = []
+        # Launch order.  Collectives must be issued in the same order on every rank, so buckets are launched in a FIXED sequence: bucket
+        # order[i] goes out when it is complete and order[0 .. i-1] are out.  The sequence starts as the arena order from the end and is
+        # replaced ONCE by the order in which rank 0 saw the buckets complete during its first full step (broadcast in finish()): arena
+        # order is registration order, not arrival order — the conv stem is registered after the Swin stages but its gradient is the last
+        # one of the step, and with the strict arena sequence the bucket that holds it held back every bucket behind it (single-rank trace,
+        # Swin-T, 32 MiB: 4 of 6 buckets = 122 of 214 MB launched within the last 0.3 ms of a 35 ms backward).
+        self.order = list(range(len(self.buckets)))
+        self._order_learned = False
+        self._completed = []
         # GE_DDP_TRACE=1: per-bucket launch / completion times of the latest step (ms since the first gradient hook of the step;
         # HIP events on the launching stream for device tensors, host clock otherwise) — makes the overlap of the exchange with
         # backward readable off a single-GPU run with GE_DDP_FORCE=1 (``bucket_trace()``)
@@ -85,6 +99,7 @@ class FlatDDP(nn.Module):
     def _reset(self):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._works, self._next = [], 0
+        self._completed = []
         self._streams = [set() for _ in self.buckets]       # HIP streams on which a bucket's gradients were accumulated
         self._trace, self._t0 = [], None
 
@@ -107,13 +122,15 @@ class FlatDDP(nn.Module):
     def describe(self):
         """Static facts of the exchange for logs / bench.py: rank count as the process group reports it, backend, bucket layout."""
         return dict(active=bool(self.active), world_size=int(self.world), backend=self.backend,
-                    wire_dtype='bf16' if self.grad_dtype is not None else 'fp32', n_buckets=len(self.buckets),
+                    wire_dtype='bf16' if self.grad_dtype is not None else 'fp32', n_buckets=len(self.buckets), launch_order=list(self.order),
                     bucket_MB=[round((hi - lo) * (2 if self.grad_dtype is not None else 4) / 2 ** 20, 2) for lo, hi, _ in self.buckets])
 
     def _make_hook(self, idx):
         def hook(param):
             b = self.bucket_of[idx]
             self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._completed.append(b)
             if self.trace_on and self._t0 is None:
                 self._t0 = self._stamp()
             if param.is_cuda:                                 # branches of the model may run (forward and backward) on side streams
@@ -147,8 +164,8 @@ class FlatDDP(nn.Module):
             self._works.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), ('scale', buf, None)))
 
     def _launch_ready(self):
-        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
-            self._launch(self._next)
+        while self._next < len(self.buckets) and self._pending[self.order[self._next]] <= 0:
+            self._launch(self.order[self._next])
             self._next += 1
 
     def finish(self):
@@ -158,7 +175,7 @@ class FlatDDP(nn.Module):
                 self.arena.collect()
             return
         while self._next < len(self.buckets):            # parameters without a gradient this step, or overlap off
-            self._launch(self._next)
+            self._launch(self.order[self._next])
             self._next += 1
         for i, (work, post) in enumerate(self._works):
             work.wait()
@@ -183,6 +200,12 @@ class FlatDDP(nn.Module):
                 rel = lambda t: (t - self._t0) * 1e3
             self.last_trace = [dict(bucket=r['bucket'], bytes=r['bytes'], params=r['params'], launch_ms=rel(r['launch']),
                                     done_ms=rel(r['done'])) for r in self._trace]
+        if not self._order_learned and len(self.buckets) > 1 and sorted(self._completed) == list(range(len(self.buckets))):
+            # every bucket completed through its hooks this step: adopt rank 0's completion order as the launch sequence from now on
+            t = torch.tensor(self._completed, dtype=torch.int64, device=self.arena.flat_grad.device)
+            dist.broadcast(t, src=0, group=self.group)
+            self.order = [int(v) for v in t.tolist()]
+            self._order_learned = True
         self._reset()
 
     # ------------------------------------------------------------------ module protocol

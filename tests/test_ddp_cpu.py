@@ -463,8 +463,8 @@ def _worker4(rank, world, port, tmp):
 
 def test_flat_ddp_gloo_world4_ragged_buckets_and_late_gradients(tmp_path):
     """World size 4 (the N = 4 point of the driver's scaling run): buckets of unequal size with a partial tail bucket, gradients
-    that become ready out of bucket order (buckets must still launch strictly in sequence on every rank — a rank-dependent
-    order would deadlock or mix slices), a parameter without a gradient on some steps (its slice must be reduced as zeros),
+    that become ready out of bucket order (buckets must launch in ONE agreed sequence on every rank — a rank-dependent
+    order would deadlock or mix slices: arena order first, then rank 0's observed completion order), a parameter without a gradient on some steps (its slice must be reduced as zeros),
     three iterations through the state machine.  Every rank must end each step with the full-batch gradient."""
     port = free_port()
     mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
@@ -483,12 +483,20 @@ def test_flat_ddp_gloo_world4_ragged_buckets_and_late_gradients(tmp_path):
         if step % 2 == 1:                                   # `skip` had no gradient: its slice is exactly zero after the exchange
             off = arena.offsets[[id(p) for p in arena.params].index(id(ref.skip.weight))]
             assert torch.count_nonzero(rs[0]['grads'][step][off:off + ref.skip.weight.numel()]) == 0
-    # the trace (GE_DDP_TRACE=1): one record per bucket and step, launched in bucket order, completion after launch
-    for r in rs:
-        for tr in r['traces']:
-            assert [t['bucket'] for t in tr] == list(range(len(r['sizes'])))
+    # the trace (GE_DDP_TRACE=1): one record per bucket and step, completion after launch; the launch sequence is the SAME on every rank
+    # in every step: arena order in the first step, then the completion order rank 0 observed in its first full step (FlatDDP.order)
+    nb = len(rs[0]['sizes'])
+    for step in range(3):
+        seq0 = [t['bucket'] for t in rs[0]['traces'][step]]
+        assert sorted(seq0) == list(range(nb))
+        if step == 0:
+            assert seq0 == list(range(nb))
+        for r in rs:
+            tr = r['traces'][step]
+            assert [t['bucket'] for t in tr] == seq0, (step, seq0)
             assert all(t['done_ms'] >= t['launch_ms'] >= 0 for t in tr)
-            assert [t['bytes'] for t in tr] == [4 * n for n in r['sizes']]
+            assert [t['bytes'] for t in tr] == [4 * r['sizes'][t['bucket']] for t in tr]
+    assert [t['bucket'] for t in rs[0]['traces'][1]] == [t['bucket'] for t in rs[0]['traces'][2]]          # learned once, then fixed
 
 
 class BNNet(nn.Module):
