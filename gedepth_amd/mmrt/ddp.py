@@ -6,9 +6,14 @@ Replaces ``MMDistributedDataParallel`` as used by depth/apis/train.py:59-67 (ref
     a *slice* of it — no flatten / unflatten copies, and buckets can be large (default 32 MiB: xGMI is
     point-to-point, 7 links x ~153 GB/s per GPU, so few, large collectives amortise per-call latency; 64 MiB was the default until the
     single-rank bucket trace showed its cost: profiles/r4_bench_ddp_forced_single_rank.json, see __init__);
-  * buckets are filled from the end of the arena (decoder / neck parameters first, the order backward
-    produces them) and launched strictly in sequence with ``async_op=True`` on RCCL's stream, overlapping the
-    rest of backward; ``finish()`` waits once before the optimizer kernel;
+  * buckets are launched strictly in sequence with ``async_op=True`` on RCCL's stream, overlapping the rest of
+    backward; ``finish()`` waits once before the optimizer kernel.  The first step runs on buckets cut from the end of
+    the arena (registration order reversed: roughly the order backward produces gradients); its hook sequence on rank 0 IS
+    the arrival order, which every rank then adopts (one collective decision): the arena is permuted into arrival order
+    once (``GradArena.permute``), so that from step 2 on a bucket is a contiguous slice of gradients that become ready
+    TOGETHER — a small first bucket (<= 8 MiB) leaves a few milliseconds into backward, and what is launched at the very
+    end of backward is one small tail bucket (round 5; until round 4 only the launch ORDER of registration-order buckets
+    was learned, and the decoder-end gradients sat in a 45 MB bucket completed by a late parameter);
   * logged scalars are reduced in one message (depther/base.py: DeferredLogVars), BatchNorm statistics stay
     per-GPU like the reference (SyncBN is configured but inactive there).
 Works with the ``gloo`` backend on CPU tensors for the world_size-2 tests.
@@ -50,56 +55,85 @@ class FlatDDP(nn.Module):
             for b in module.buffers():
                 if b.is_floating_point():
                     dist.broadcast(b, src=0, group=process_group)
-        # buckets: contiguous arena slices, built from the END (reverse registration order)
-        cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
-        slices = arena.slices()
-        self.buckets, self.bucket_of = [], {}
-        end = arena.numel
-        members = []
-        for idx in range(len(slices) - 1, -1, -1):
-            off, _ = slices[idx]
-            members.append(idx)
-            if end - off >= cap or idx == 0:
-                self.buckets.append((off, end, list(members)))
-                for m in members:
-                    self.bucket_of[m] = len(self.buckets) - 1
-                end, members = off, []
-        # the arena starts with the patch-embed / stage-0 parameters: built from the end, the LAST bucket would be a sliver (< 1 MB for
-        # Swin-T at 64 MiB buckets, 19 MB at 32 MiB) whose collective starts when backward is already over — a latency-bound all-reduce that nothing
-        # overlaps.  A tail below a quarter of the bucket size joins its neighbour (the slices are contiguous).
-        if len(self.buckets) >= 2 and (self.buckets[-1][1] - self.buckets[-1][0]) * 4 < cap:
-            (lo2, _, m2), (_, hi1, m1) = self.buckets.pop(), self.buckets.pop()
-            self.buckets.append((lo2, hi1, m1 + m2))
-            for m in m1 + m2:
-                self.bucket_of[m] = len(self.buckets) - 1
-        self._pending = [0] * len(self.buckets)
-        self._works = []
-        self._next = 0
+        self._cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        # arrival-order layout (after the first step): first and last bucket at most this many elements (the first should leave
+        # early, the last is what nothing overlaps); GE_DDP_EDGE_MB overrides, 0 disables the re-layout
+        self._edge = int(float(os.environ.get('GE_DDP_EDGE_MB', 8)) * 1024 * 1024 // 4)
         self._hooks = []
+        self._build_buckets(arrival_layout=False)
         # Launch order.  Collectives must be issued in the same order on every rank, so buckets are launched in a FIXED sequence: bucket
-        # order[i] goes out when it is complete and order[0 .. i-1] are out.  The sequence starts as the arena order from the end and is
-        # replaced ONCE by the order in which rank 0 saw the buckets complete during its first full step (broadcast in finish()): arena
-        # order is registration order, not arrival order — the conv stem is registered after the Swin stages but its gradient is the last
-        # one of the step, and with the strict arena sequence the bucket that holds it held back every bucket behind it (single-rank trace,
-        # Swin-T, 32 MiB: 4 of 6 buckets = 122 of 214 MB launched within the last 0.3 ms of a 35 ms backward).
-        self.order = list(range(len(self.buckets)))
+        # order[i] goes out when it is complete and order[0 .. i-1] are out.  Until the arrival order is learned this is the arena order
+        # from the end; afterwards the arena itself is in arrival order and the sequence is 0, 1, 2, ...
         self._order_learned = False
-        self._completed = []
+        self._arrival = []
         # GE_DDP_TRACE=1: per-bucket launch / completion times of the latest step (ms since the first gradient hook of the step;
         # HIP events on the launching stream for device tensors, host clock otherwise) — makes the overlap of the exchange with
         # backward readable off a single-GPU run with GE_DDP_FORCE=1 (``bucket_trace()``)
         self.trace_on = os.environ.get('GE_DDP_TRACE') == '1'
         self._trace, self.last_trace = [], []
-        if self.active:
-            for idx, p in enumerate(arena.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+        self._register_hooks()
         self._reset()
+
+    def _build_buckets(self, arrival_layout):
+        """Cut the arena into contiguous buckets.  ``arrival_layout`` False: registration-order arena, buckets from the END (bucket 0 =
+        the last-registered parameters, whose gradients come first), a sliver at the front joins its neighbour.  True: the arena is in
+        arrival order, buckets from the START; the first and the last bucket hold at most ``_edge`` elements."""
+        arena, cap = self.arena, self._cap
+        slices = arena.slices()
+        n = len(slices)
+        ends = [slices[i + 1][0] if i + 1 < n else arena.numel for i in range(n)]      # slice end incl. alignment padding
+        self.buckets, self.bucket_of = [], {}
+
+        def close(lo, hi, members):
+            self.buckets.append((lo, hi, list(members)))
+            for m in members:
+                self.bucket_of[m] = len(self.buckets) - 1
+        if not arrival_layout:
+            end, members = arena.numel, []
+            for idx in range(n - 1, -1, -1):
+                off = slices[idx][0]
+                members.append(idx)
+                if end - off >= cap or idx == 0:
+                    close(off, end, members)
+                    end, members = off, []
+            # built from the end, the LAST bucket would be a sliver whose collective starts when backward is already over: a tail below a
+            # quarter of the bucket size joins its neighbour (the slices are contiguous)
+            if len(self.buckets) >= 2 and (self.buckets[-1][1] - self.buckets[-1][0]) * 4 < cap:
+                (lo2, _, m2), (_, hi1, m1) = self.buckets.pop(), self.buckets.pop()
+                close(lo2, hi1, m1 + m2)
+        else:
+            edge = min(self._edge, cap) if self._edge > 0 else cap
+            # the tail bucket: the last arrivals, at most `edge` elements (at least one parameter)
+            tail_from = n - 1
+            while tail_from > 0 and arena.numel - slices[tail_from - 1][0] <= edge:
+                tail_from -= 1
+            lo, members, limit = 0, [], edge
+            for idx in range(tail_from):
+                if members and ends[idx] - lo > limit:
+                    close(lo, slices[idx][0], members)
+                    lo, members, limit = slices[idx][0], [], cap
+                members.append(idx)
+            if members:
+                close(lo, slices[tail_from][0], members)
+            close(slices[tail_from][0], arena.numel, list(range(tail_from, n)))
+        self.order = list(range(len(self.buckets)))
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self._next = 0
+
+    def _register_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self.active:
+            for idx, p in enumerate(self.arena.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
 
     # ------------------------------------------------------------------ bucket state machine
     def _reset(self):
         self._pending = [len(m) for _, _, m in self.buckets]
         self._works, self._next = [], 0
-        self._completed = []
+        self._arrival = []
         self._streams = [set() for _ in self.buckets]       # HIP streams on which a bucket's gradients were accumulated
         self._trace, self._t0 = [], None
 
@@ -129,8 +163,8 @@ class FlatDDP(nn.Module):
         def hook(param):
             b = self.bucket_of[idx]
             self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._completed.append(b)
+            if not self._order_learned:
+                self._arrival.append(idx)
             if self.trace_on and self._t0 is None:
                 self._t0 = self._stamp()
             if param.is_cuda:                                 # branches of the model may run (forward and backward) on side streams
@@ -200,13 +234,36 @@ class FlatDDP(nn.Module):
                 rel = lambda t: (t - self._t0) * 1e3
             self.last_trace = [dict(bucket=r['bucket'], bytes=r['bytes'], params=r['params'], launch_ms=rel(r['launch']),
                                     done_ms=rel(r['done'])) for r in self._trace]
-        if not self._order_learned and len(self.buckets) > 1 and sorted(self._completed) == list(range(len(self.buckets))):
-            # every bucket completed through its hooks this step: adopt rank 0's completion order as the launch sequence from now on
-            t = torch.tensor(self._completed, dtype=torch.int64, device=self.arena.flat_grad.device)
-            dist.broadcast(t, src=0, group=self.group)
-            self.order = [int(v) for v in t.tolist()]
-            self._order_learned = True
+        if not self._order_learned:
+            self._learn_arrival_order()
         self._reset()
+
+    def _learn_arrival_order(self):
+        """End of a step, order not yet learned.  EVERY rank takes part in one broadcast from rank 0 — whatever happened locally — so
+        the decision is collective: rank 0 sends [valid, arrival sequence]; valid = each of its parameters reported exactly once this
+        step (a parameter without a gradient in that step makes the sequence incomplete: try again next step).  All ranks then
+        permute their arenas identically and re-cut the buckets.  (Round 4 let each rank decide from its own hook history whether to
+        enter the broadcast; ranks that disagreed — e.g. a data-dependent branch — would have hung or paired it with a later
+        all-reduce.)"""
+        n = len(self.arena.params)
+        msg = torch.zeros(n + 1, dtype=torch.int64)
+        if sorted(self._arrival) == list(range(n)):
+            msg[0] = 1
+            msg[1:] = torch.tensor(self._arrival, dtype=torch.int64)
+        dev = self.arena.flat_grad.device
+        msg = msg.to(dev)
+        dist.broadcast(msg, src=0, group=self.group)
+        msg = msg.cpu()
+        if int(msg[0]) != 1:
+            return
+        seq = [int(v) for v in msg[1:].tolist()]
+        self._order_learned = True
+        self.arrival_order = seq
+        if self._edge <= 0:                              # re-layout disabled: keep the registration-order buckets, learn nothing else
+            return
+        self.arena.permute(seq)
+        self._build_buckets(arrival_layout=True)
+        self._register_hooks()
 
     # ------------------------------------------------------------------ module protocol
     def forward(self, *args, **kwargs):

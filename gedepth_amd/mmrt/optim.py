@@ -115,6 +115,60 @@ class GradArena:
     def slices(self):
         return [(off, p.numel()) for p, off in zip(self.params, self.offsets)]
 
+    def on_permute(self, callback):
+        """Register ``callback(remap)``, called after ``permute``: ``remap(buf)`` returns the re-ordered copy of any flat buffer
+        laid out like this arena before the permutation (optimizer moments, weight-decay mask)."""
+        self._permute_callbacks = getattr(self, '_permute_callbacks', []) + [callback]
+
+    @torch.no_grad()
+    def permute(self, order):
+        """Re-order the slices of the arena: ``order[i]`` = current index of the parameter that comes i-th afterwards.  Parameter,
+        gradient and shadow values move with their slices; ``p.data`` / ``p.grad`` / ``p._ge_lp`` are re-pointed.  Used once by
+        FlatDDP after the first step, when the order in which backward delivers the gradients is known: buckets are contiguous
+        slices, so the arena must be in ARRIVAL order for the first bucket to be complete early (gedepth_amd/mmrt/ddp.py)."""
+        n = len(self.params)
+        assert sorted(order) == list(range(n)), 'permute() needs a permutation of the parameter indices'
+        if list(order) == list(range(n)):
+            return
+        align_sizes = [(self.offsets[i + 1] if i + 1 < n else self.numel) - self.offsets[i] for i in range(n)]
+        old_off = list(self.offsets)
+        new_off, pos = [0] * n, 0
+        for j, i in enumerate(order):
+            new_off[j] = pos
+            pos += align_sizes[i]
+        assert pos == self.numel
+        # one gather index instead of ~500 slice copies: src[k] = old position of the element that lands at k
+        src = torch.empty(self.numel, dtype=torch.int64)
+        for j, i in enumerate(order):
+            src[new_off[j]:new_off[j] + align_sizes[i]] = torch.arange(old_off[i], old_off[i] + align_sizes[i])
+        src = src.to(self.flat_param.device)
+
+        def remap(buf):
+            assert buf.numel() == self.numel
+            return buf.index_select(0, src)
+        has_grad = [p.grad is not None for p in self.params]
+        self.collect()                                   # every live gradient into its (old) slice before the slices move
+        self.flat_param = remap(self.flat_param)
+        self.flat_grad = remap(self.flat_grad)
+        shadow = getattr(self, 'flat_shadow', None)
+        if shadow is not None:
+            self.flat_shadow = remap(shadow)
+        self.params = [self.params[i] for i in order]
+        has_grad = [has_grad[i] for i in order]
+        self.offsets = new_off
+        self.views = []
+        for p, off, hg in zip(self.params, self.offsets, has_grad):
+            current = getattr(p, '_ge_lp_version', None) == p._version
+            p.data = self._view(self.flat_param, off, p)
+            view = self._view(self.flat_grad, off, p)
+            self.views.append(view)
+            p.grad = view if (hg or not self.adopt) else None
+            if shadow is not None:
+                p._ge_lp = self._view(self.flat_shadow, off, p)
+                p._ge_lp_version = p._version if current else -1
+        for cb in getattr(self, '_permute_callbacks', []):
+            cb(remap)
+
 
 def lowp(p, dtype):
     """``p.to(dtype)`` served from the optimizer's bf16 shadow arena when it is current (no kernel), else a cast."""
@@ -159,6 +213,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if bf16_shadow:                            # 2 B / parameter: the autocast forward reads weights from here, no per-tensor casts
             self.arena.enable_shadow()
             self.arena.refresh_shadow(copy=True)
+        self.arena.on_permute(self._arena_permuted)
+
+    def _arena_permuted(self, remap):
+        """The arena changed its slice order (FlatDDP: arrival order): the moments and the decay mask follow their parameters."""
+        self.exp_avg, self.exp_avg_sq, self.wd_mask = remap(self.exp_avg), remap(self.exp_avg_sq), remap(self.wd_mask)
 
     def sync_grads_from_params(self):
         self.arena.reattach()

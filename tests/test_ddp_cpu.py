@@ -43,6 +43,12 @@ class Toy(nn.Module):
         return dict(loss=l, log_vars=lv, num_samples=len(batch['x']))
 
 
+def reg_grad(model):
+    """The gradient as one vector in REGISTRATION order, whatever order the arena's slices are in (FlatDDP permutes the arena into
+    gradient-arrival order after its first step)."""
+    return torch.cat([p.grad.detach().reshape(-1) for p in model.parameters()])
+
+
 class ArenaSGD:
     """Minimal optimizer over a GradArena for the CPU tests (the product's FusedAdamW is MI355X-only)."""
 
@@ -81,14 +87,15 @@ def _worker(rank, world, port, tmp, adopt=None):
     out['loss'].backward()
     ddp.finish()
     res = dict(params={k: v.clone() for k, v in model.state_dict().items()},
-               grad=opt.arena.flat_grad.clone(), log=dict(out['log_vars']), local_loss=out['loss'].item())
+               grad=reg_grad(model).clone(), log=dict(out['log_vars']), local_loss=out['loss'].item())
     # second iteration exercises the bucket state reset
     opt.step()
     opt.zero_grad()
     out = ddp.train_step(batch)
     out['loss'].backward()
     ddp.finish()
-    res['grad2'] = opt.arena.flat_grad.clone()
+    res['grad2'] = reg_grad(model).clone()
+    assert ddp._order_learned and ddp.describe()['launch_order'] == list(range(len(ddp.buckets)))
     torch.save(res, os.path.join(tmp, f'r{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
@@ -112,9 +119,8 @@ def test_flat_ddp_gloo_world2(tmp_path, adopt):
     ref.load_state_dict(r0['params'])
     g = torch.Generator().manual_seed(0)
     X, Y = torch.randn(8, 8, generator=g), torch.randn(8, 1, generator=g)
-    arena = GradArena(ref.parameters())
     (ref(X) - Y).pow(2).mean().backward()
-    assert torch.allclose(arena.flat_grad, r0['grad'], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(reg_grad(ref), r0['grad'], rtol=1e-5, atol=1e-7)
     # log vars: mean over ranks, one fused all-reduce
     assert abs(r0['log']['loss'] - 0.5 * (r0['local_loss'] + r1['local_loss'])) < 1e-6
     assert abs(r0['log']['aux'] - 2 * r0['log']['loss_mse']) < 1e-6
@@ -134,9 +140,10 @@ def _worker_bf16(rank, world, port, tmp):
     opt.zero_grad()
     out = ddp.train_step(batch)
     out['loss'].backward()
-    local = opt.arena.flat_grad.clone()
+    opt.arena.collect()
+    local = reg_grad(model).clone()
     ddp.finish()
-    torch.save(dict(local=local, reduced=opt.arena.flat_grad.clone()), os.path.join(tmp, f'b{rank}.pt'))
+    torch.save(dict(local=local, reduced=reg_grad(model).clone()), os.path.join(tmp, f'b{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -432,6 +439,12 @@ class Branchy(nn.Module):
         return self.late(y)
 
 
+# which ranks run the `skip` branch in which step: step 0 leaves rank 0 WITHOUT a gradient for `skip` (rank 0's arrival sequence is
+# incomplete -> nobody may adopt an order), step 1 leaves rank 1 without it while rank 0 is complete (every rank must adopt rank 0's
+# sequence, rank 1 included, although its own hook history is incomplete: the decision is collective, not per rank)
+_SKIP_PLAN = [(False, True, True, True), (True, False, True, True), (False, False, False, False), (True, True, True, True)]
+
+
 def _worker4(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GE_DDP_TRACE='1')
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -444,18 +457,24 @@ def _worker4(rank, world, port, tmp):
     # neighbour (a tail below a quarter of the bucket size would be a lone latency-bound collective after backward has ended)
     assert sizes == [33, 35, 46] and sum(sizes) == arena.numel, sizes
     assert sorted(ddp.buckets[-1][2]) == [0, 1, 2, 3] and ddp.describe()['n_buckets'] == 3
+    names = {id(p): n for n, p in model.named_parameters()}
     g = torch.Generator().manual_seed(1)
     X, Y = torch.randn(16, 3, generator=g), torch.randn(16, 1, generator=g)
-    res = dict(sizes=sizes, grads=[], traces=[])
-    for step in range(3):
+    res = dict(sizes=sizes, grads=[], traces=[], learned=[], layout=[], values=[])
+    for step, plan in enumerate(_SKIP_PLAN):
         arena.zero_grad()
-        use_skip = step % 2 == 0
-        loss = (ddp(X[rank * 4:(rank + 1) * 4], use_skip) - Y[rank * 4:(rank + 1) * 4]).pow(2).mean()
+        loss = (ddp(X[rank * 4:(rank + 1) * 4], plan[rank]) - Y[rank * 4:(rank + 1) * 4]).pow(2).mean()
         loss.backward()
         ddp.finish()
-        res['grads'].append(arena.flat_grad.clone())
+        res['grads'].append({names[id(p)]: v.clone() for p, v in zip(arena.params, arena.views)})
         res['traces'].append(ddp.bucket_trace())
-    res['params'] = {k: v.clone() for k, v in model.state_dict().items()}
+        res['learned'].append(bool(ddp._order_learned))
+        res['layout'].append(dict(order=[names[id(p)] for p in arena.params], sizes=[hi - lo for lo, hi, _ in ddp.buckets]))
+        # parameter VALUES travel with their slices, and p.data / p.grad stay views of the (new) arena
+        assert all(p.data_ptr() == arena.flat_param[o:o + 1].data_ptr() for p, o in zip(arena.params, arena.offsets))
+        with torch.no_grad():
+            arena.flat_param.add_(arena.flat_grad, alpha=-0.05)      # a plain SGD step through the arena
+        res['values'].append({n: p.detach().clone() for n, p in model.named_parameters()})
     torch.save(res, os.path.join(tmp, f'w{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
@@ -463,40 +482,60 @@ def _worker4(rank, world, port, tmp):
 
 def test_flat_ddp_gloo_world4_ragged_buckets_and_late_gradients(tmp_path):
     """World size 4 (the N = 4 point of the driver's scaling run): buckets of unequal size with a partial tail bucket, gradients
-    that become ready out of bucket order (buckets must launch in ONE agreed sequence on every rank — a rank-dependent
-    order would deadlock or mix slices: arena order first, then rank 0's observed completion order), a parameter without a gradient on some steps (its slice must be reduced as zeros),
-    three iterations through the state machine.  Every rank must end each step with the full-batch gradient."""
+    that become ready out of bucket order, a parameter without a gradient on SOME RANKS in some steps (its slice is reduced as zeros
+    there), four iterations.  The arrival order is adopted by a collective decision: only when rank 0's sequence is complete, by every
+    rank in the same step, whatever each rank saw locally; the arena is then permuted into arrival order and re-cut into buckets.
+    Every rank must end each step with the mean of the per-rank gradients, and training through the permuted arena must equal
+    training a plain replica."""
     port = free_port()
     mp.spawn(_worker4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
     rs = [torch.load(tmp_path / f'w{i}.pt', weights_only=False) for i in range(4)]
-    ref = Branchy()
-    ref.load_state_dict(rs[0]['params'])
-    arena = GradArena(ref.parameters(), align=1, adopt=False)
     g = torch.Generator().manual_seed(1)
     X, Y = torch.randn(16, 3, generator=g), torch.randn(16, 1, generator=g)
-    for step in range(3):
+    torch.manual_seed(3)                                    # rank 0's initial weights were broadcast to everyone
+    ref = Branchy()
+    for step, plan in enumerate(_SKIP_PLAN):
         for r in rs[1:]:
-            assert torch.equal(r['grads'][step], rs[0]['grads'][step]), step
-        arena.flat_grad.zero_()
-        (ref(X, step % 2 == 0) - Y).pow(2).mean().backward()
-        assert torch.allclose(arena.flat_grad, rs[0]['grads'][step], rtol=1e-5, atol=1e-7), step
-        if step % 2 == 1:                                   # `skip` had no gradient: its slice is exactly zero after the exchange
-            off = arena.offsets[[id(p) for p in arena.params].index(id(ref.skip.weight))]
-            assert torch.count_nonzero(rs[0]['grads'][step][off:off + ref.skip.weight.numel()]) == 0
+            assert r['grads'][step].keys() == rs[0]['grads'][step].keys()
+            assert all(torch.equal(r['grads'][step][k], v) for k, v in rs[0]['grads'][step].items()), step
+        want = {n: torch.zeros_like(p) for n, p in ref.named_parameters()}
+        for rank in range(4):
+            ref.zero_grad()
+            (ref(X[rank * 4:(rank + 1) * 4], plan[rank]) - Y[rank * 4:(rank + 1) * 4]).pow(2).mean().backward()
+            for n, p in ref.named_parameters():
+                if p.grad is not None:
+                    want[n] += p.grad / 4
+        for n, v in want.items():
+            assert torch.allclose(rs[0]['grads'][step][n], v, rtol=1e-5, atol=1e-7), (step, n)
+        if not any(plan):                                    # `skip` had no gradient anywhere: its slice is exactly zero after the exchange
+            assert torch.count_nonzero(rs[0]['grads'][step]['skip.weight']) == 0
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                p.add_(want[n], alpha=-0.05)
+        for n, p in ref.named_parameters():
+            assert torch.allclose(rs[2]['values'][step][n], p.detach(), rtol=1e-5, atol=1e-6), (step, n)
+    # collective decision: step 0 (rank 0 incomplete) nobody learns; step 1 (rank 0 complete, rank 1 not) EVERYBODY does
+    for r in rs:
+        assert r['learned'] == [False, True, True, True]
+        assert r['layout'] == rs[0]['layout']
+    reg = ['late.weight', 'late.bias', 'body.weight', 'body.bias', 'skip.weight', 'skip.bias', 'early.weight', 'early.bias']
+    assert rs[0]['layout'][0]['order'] == reg and rs[0]['layout'][0]['sizes'] == [33, 35, 46]
+    arr = rs[0]['layout'][1]['order']
+    # arrival order of rank 0's step 1: the `late` head first, `early` last (registration order has it the other way round)
+    assert sorted(arr) == sorted(reg) and arr != reg
+    assert {arr[0], arr[1]} == {'late.weight', 'late.bias'} and {arr[-1], arr[-2]} == {'early.weight', 'early.bias'}
+    assert rs[0]['layout'][1] == rs[0]['layout'][2] == rs[0]['layout'][3]                 # learned once, then fixed
+    new_sizes = rs[0]['layout'][1]['sizes']
+    assert sum(new_sizes) == 114 and new_sizes[0] <= 30 and new_sizes[-1] <= 30, new_sizes
     # the trace (GE_DDP_TRACE=1): one record per bucket and step, completion after launch; the launch sequence is the SAME on every rank
-    # in every step: arena order in the first step, then the completion order rank 0 observed in its first full step (FlatDDP.order)
-    nb = len(rs[0]['sizes'])
-    for step in range(3):
+    for step in range(4):
         seq0 = [t['bucket'] for t in rs[0]['traces'][step]]
-        assert sorted(seq0) == list(range(nb))
-        if step == 0:
-            assert seq0 == list(range(nb))
+        nb = len(rs[0]['layout'][step - 1]['sizes']) if step else 3       # a step runs on the layout the previous step left
+        assert seq0 == list(range(nb)), (step, seq0)
         for r in rs:
             tr = r['traces'][step]
             assert [t['bucket'] for t in tr] == seq0, (step, seq0)
             assert all(t['done_ms'] >= t['launch_ms'] >= 0 for t in tr)
-            assert [t['bytes'] for t in tr] == [4 * r['sizes'][t['bucket']] for t in tr]
-    assert [t['bucket'] for t in rs[0]['traces'][1]] == [t['bucket'] for t in rs[0]['traces'][2]]          # learned once, then fixed
 
 
 class BNNet(nn.Module):
@@ -539,3 +578,44 @@ def test_eval_hook_broadcasts_bn_buffers_before_distributed_eval(tmp_path):
     for k, i in (('mean', 0), ('var', 1)):
         assert torch.equal(r0['seen'][k], r0['before'][i])           # rank 0 keeps its own statistics
         assert torch.equal(r1['seen'][k], r0['before'][i])           # rank 1 evaluates with rank 0's
+
+
+def test_grad_arena_permute_moves_values_views_shadow_and_followers():
+    """GradArena.permute (FlatDDP's arrival-order re-layout): parameter / gradient / bf16-shadow values travel with their slices,
+    ``p.data`` / ``p.grad`` / ``p._ge_lp`` are views of the new buffers (channels-last convolution weights keep their NHWC slice order),
+    registered followers (optimizer moments) are remapped with the same index, and a second permutation composes."""
+    from gedepth_amd.mmrt.optim import lowp
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(4, 6, 3), nn.Linear(5, 3), nn.LayerNorm(7))
+    net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
+    arena = GradArena(net.parameters(), align=8, adopt=False)
+    arena.enable_shadow()
+    arena.refresh_shadow(copy=True)
+    follower = {'m': torch.arange(arena.numel, dtype=torch.float32)}
+    arena.on_permute(lambda remap: follower.update(m=remap(follower['m'])))
+    params = list(net.parameters())
+    want_p = [p.detach().clone() for p in params]
+    for i, p in enumerate(params):
+        p.grad.fill_(float(i + 1))
+    old = {id(p): (off, p.numel()) for p, off in zip(arena.params, arena.offsets)}
+    order = [3, 0, 5, 1, 4, 2]
+    arena.permute(order)
+    assert [id(p) for p in arena.params] == [id(params[i]) for i in order]
+    for i, p in enumerate(params):
+        j = [id(q) for q in arena.params].index(id(p))
+        off = arena.offsets[j]
+        assert torch.equal(p.detach(), want_p[i]) and bool((p.grad == i + 1).all())
+        assert p.data_ptr() == arena.flat_param[off:off + 1].data_ptr() and p.grad.data_ptr() == arena.flat_grad[off:off + 1].data_ptr()
+        assert p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
+        assert lowp(p, torch.bfloat16).data_ptr() == arena.flat_shadow[off:off + 1].data_ptr()        # shadow still current
+        assert torch.equal(p._ge_lp, p.detach().to(torch.bfloat16))
+        o0, n = old[id(p)]
+        assert torch.equal(follower['m'][off:off + n], torch.arange(o0, o0 + n, dtype=torch.float32))   # follower moved identically
+    # autograd still accumulates into the (new) arena
+    before = arena.flat_grad.clone()
+    net[1](torch.ones(2, 5)).sum().backward()
+    assert not torch.equal(before, arena.flat_grad)
+    arena.permute([5, 4, 3, 2, 1, 0])
+    assert all(torch.equal(p.detach(), w) for p, w in zip(params, want_p))
+    with pytest.raises(AssertionError):
+        arena.permute([0, 0, 1, 2, 3, 4])
