@@ -390,6 +390,7 @@ struct MmBwdArgs {
   MmArgs f;                                   // forward inputs (out / loc_out / attw_out unused)
   const bf16_t* gout;                         // (B, Nq, nH*64)
   bf16_t* d_off; long d_off_ld; bf16_t* d_logit; long d_logit_ld;
+  int4* bbox;                                 // optional: tap boxes (two point groups) of every (image, head, level, tile) for the d_value kernel below
 };
 #define MM_SIMG ((MM_CAP + 1) * 32)           // fp32 elements: [window row][32 queries] + one dump row
 
@@ -439,11 +440,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
       int pk[8];
       float fx[8], fy[8], awl[8];
       int bmin, bmax;
+      int gmin0 = 0, gmax0 = 0, gmin1 = 0, gmax1 = 0;                      // boxes of the two point groups (0-3, 4-7)
       {
         const uint32_t u[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
         const float fW = (float)Wl, fH = (float)Hl;
         const float rW = 1.f / fW, rH = 1.f / fH;
         int xmn = 32767, ymn = 32767, xmx = -32768, ymx = -32768;
+        int xmn1 = 32767, ymn1 = 32767, xmx1 = -32768, ymx1 = -32768;
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           awl[p] = s ? aw[1][p] : aw[0][p];
@@ -462,9 +465,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
                         (in && y0 + 1 < Hl && x0 + 1 < Wl ? 8 : 0);
           pk[p] = xa | (ya << 13) | (m << 26) | ((xb - xa) << 30) | ((yb - ya) << 31);     // xa, ya < 2^13 (launcher)
           if (in) { xmn = min(xmn, xa); xmx = max(xmx, xb); ymn = min(ymn, ya); ymx = max(ymx, yb); }
+          if (p == 3) { gmin0 = (ymn << 16) | (xmn & 0xffff); gmax0 = (ymx << 16) | (xmx & 0xffff); }   // box of points 0-3 (d_value kernel)
+          if (p >= 4 && in) { xmn1 = min(xmn1, xa); xmx1 = max(xmx1, xb); ymn1 = min(ymn1, ya); ymx1 = max(ymx1, yb); }
         }
         bmin = (ymn << 16) | (xmn & 0xffff);
         bmax = (ymx << 16) | (xmx & 0xffff);
+        gmin1 = (ymn1 << 16) | (xmn1 & 0xffff); gmax1 = (ymx1 << 16) | (xmx1 & 0xffff);
         if (s == 0) {
           o0 = *(const uint4*)(op + 16); o1 = *(const uint4*)(op + 24);
           rx = rp[a.ref_sl]; ry = rp[a.ref_sl + 1];
@@ -480,6 +486,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
       w.bwA = anyA ? xmaxA - w.xminA + 1 : 0; w.bwB = anyB ? xmaxB - w.xminB + 1 : 0;
       w.KA = anyA ? w.bwA * (ymaxA - w.yminA + 1) : 0; w.KB = anyB ? w.bwB * (ymaxB - w.yminB + 1) : 0;
       w.Ktot = w.KA + w.KB;
+      if (ba.bbox) {                              // uniform.  Tap boxes of the point groups 0-3 / 4-7 of every (image, head, level, tile):
+        // (min y << 16 | min x, max y << 16 | max x) x 2, INT16 extremes when no tap of the group is inside the map
+        gmin0 = mm_half_reduce<false>(gmin0); gmax0 = mm_half_reduce<true>(gmax0);
+        gmin1 = mm_half_reduce<false>(gmin1); gmax1 = mm_half_reduce<true>(gmax1);
+        if ((lane & 31) == 31)
+          ba.bbox[((long)bh * 4 + s + 2 * hv) * a.ntiles + tile] = make_int4(gmin0, gmax0, gmin1, gmax1);
+      }
       float sv[8], sx[8], sy[8];
 #pragma unroll
       for (int p = 0; p < 8; ++p) { sv[p] = 0.f; sx[p] = 0.f; sy[p] = 0.f; }
@@ -652,8 +665,8 @@ extern "C" int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const vo
 // produced here (ge_msda_bwd_value_* / the binned path).
 extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
                                  long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order,
-                                 const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, int B, int Nv,
-                                 int Nq, int nH, int L, int P, int dtype, void* stream) {
+                                 const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, void* workspace,
+                                 int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
   if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_off_raw || !d_logit_raw || B < 0 || Nq < 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
@@ -671,5 +684,391 @@ extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const
   a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0;
   ba.gout = (const bf16_t*)d_out;
   ba.d_off = (bf16_t*)d_off_raw; ba.d_off_ld = d_off_ld; ba.d_logit = (bf16_t*)d_logit_raw; ba.d_logit_ld = d_logit_ld;
+  ba.bbox = (int4*)workspace;                  // head of the ge_msda_bwd_mm_workspace layout (mv_ws_layout)
   return msda_mm_bwd_lw_launch(ba, ge_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------ d_value (round 5)
+// Gradient of the sampling w.r.t. the value rows as the TRANSPOSE of the forward contraction,
+//
+//     dV_win[r, ch] = sum_q C[q, r] * dO[q, ch]        r: rows of a value window, q: queries, ch: 64 channels of the head
+//
+// with C the same coefficient image as in msda_mm_fwd_k.  Replaces, for the cross-attention, the count -> scan -> fill -> drain record
+// pipeline (ge_msda_bwd_value_raw: 2.3 GB of 8-byte records written and read, 36 GB of L2-level gradient-row gathers per launch).
+//
+// The catch is where the result goes.  fp32 row atomics top out at 5.1 G wave-instructions/s chip-wide whatever the address pattern
+// (tools/ubench/hip/atomics_xcd.hip: XCD-private rows, L2-resident footprints, half rows — all the same; the limit is per CU, ~120
+// cycles per instruction), so flushing the window of every 32-query tile would cost more than the record pipeline.  Queries are
+// processed in the order of the cell of their reference point, so CONSECUTIVE tiles sample nearly the same window: a wave takes a RUN
+// of consecutive tiles of one (image, head, level) whose union window has at most MV_CAP rows, keeps dV_win of the whole run in MFMA
+// accumulators (MV_CAP / 32 row blocks x 64 channels), and flushes once per run, skipping rows nothing was added to.  Runs are cut
+// greedily (msda_mm_runs_k) from the per-tile tap boxes that msda_mm_bwd_lw_k leaves in the workspace; a single tile whose window
+// exceeds MV_CAP rows forms its own run and is walked in chunks of MV_CAP rows (correct for any geometry, fast when the order gives
+// locality).
+//
+//   window = TWO boxes concatenated along the row axis: the taps of points 0-3 and of points 4-7 of the level.  mmcv initialises the
+//            offsets of point p as (p + 1) x the head's direction, so the 8 points of a diagonal head sweep a 9 x 9 box of which they
+//            touch ~20 rows; the two half sweeps are 5 x 5 each.  (Rows that appear in both boxes are simply added twice by the flush.)
+//   wave   = one run; lane = (query q = lane & 31, group g = lane >> 5): the 4 points of its group, scattered into ITS box's rows of
+//            column q of the image [window row][32 queries] (bf16, 80-byte rows) — the two lanes of a query never meet
+//   A      = 8 consecutive queries of a window row: plain 16-byte LDS reads; B = the tile's 32 gradient rows, staged by LDS-DMA as
+//            [half][query][32 channels] and read through ds_read_b64_tr_b16; 4 MFMA 32x32x16 per 32 window rows and tile
+//   loads  = two tiles ahead: the order entry of tile i + 2 and the raw projections of tile i + 1 are issued together with the
+//            gradient-row DMA of tile i, before the tap arithmetic of tile i
+// Numerics: as the forward (f16 corner products accumulated in a bf16 image, fp32 sums); the record path rounded weights to bf16 and
+// the bilinear fractions to 8 bits.
+#ifndef MV_CAP
+#define MV_CAP 96                          // window rows held in accumulators (multiple of 32)
+#endif
+#define MV_NB (MV_CAP / 32)
+#define MV_RMAX 32                         // tiles per run at most (bounds the tail of the dynamic schedule)
+#define MV_CROW 40                         // bf16 elements per image row: 32 queries + 16 bytes of pad (conflict-free ds_read_b128 over 16 rows)
+#define MV_CIMG ((MV_CAP + 4) * MV_CROW)   // + 4 dump rows
+#define MV_HALF (32 * 32 + 32)             // stage of one channel half: [32 queries][32 channels] + 64 B skew
+#define MV_EMPTY_MIN ((32767 << 16) | 32767)
+#define MV_EMPTY_MAX ((int)0x80008000)
+#ifndef MV_DIAG
+#define MV_DIAG 0                          // measurement aid: 1 no gradient-row DMA, 2 no scatter, 4 no MFMA, 8 no flush, 16 no image clear
+#endif
+
+struct MvWs { int4* bbox; int4* runs; int* ctrl; long runs_cap; };      // ctrl[x] = runs of XCD x, ctrl[8 + x] = its work cursor,
+                                                                         // ctrl[16] = window rows flushed, ctrl[17] = tile passes (statistics)
+static size_t mv_ws_layout(int B, int Nq, int nH, char* base, MvWs* ws, size_t* ctrl_off = nullptr) {
+  const long ntiles = (Nq + 31) / 32, segs = (long)B * nH * 4;
+  const long cap = (segs + MSDA_XCDS - 1) / MSDA_XCDS * ntiles;           // runs of one XCD's segments at most
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_bbox = take((size_t)segs * ntiles * sizeof(int4));
+  const size_t o_runs = take((size_t)MSDA_XCDS * cap * 2 * sizeof(int4));
+  const size_t o_ctrl = take(32 * sizeof(int));
+  if (ctrl_off) *ctrl_off = o_ctrl;
+  if (ws) { ws->bbox = (int4*)(base + o_bbox); ws->runs = (int4*)(base + o_runs); ws->ctrl = (int*)(base + o_ctrl); ws->runs_cap = cap; }
+  return off;
+}
+
+struct MvBox { int x0, y0, x1, y1; };
+__device__ __forceinline__ MvBox mv_unpack(int mn, int mx) { return MvBox{(short)(mn & 0xffff), mn >> 16, (short)(mx & 0xffff), mx >> 16}; }
+__device__ __forceinline__ bool mv_some(const MvBox& b) { return b.x1 >= b.x0 && b.y1 >= b.y0; }
+__device__ __forceinline__ int mv_rows(const MvBox& b) { return mv_some(b) ? (b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) : 0; }
+__device__ __forceinline__ MvBox mv_join(const MvBox& a, const MvBox& b) {
+  if (!mv_some(b)) return a;
+  if (!mv_some(a)) return b;
+  return MvBox{min(a.x0, b.x0), min(a.y0, b.y0), max(a.x1, b.x1), max(a.y1, b.y1)};
+}
+
+// One wave per (image, head, level): walks the tiles in order and cuts them into runs whose two union boxes have at most MV_CAP rows
+// together (a tile that alone exceeds it: a run of its own, chunked by the consumer).  Runs without any tap inside the map are dropped.
+// Record (2 x int4): {segment = (image * nH + head) * 4 + level, first tile | tiles << 24, box 0: min y << 16 | min x, height << 16 | width},
+//                    {box 1: min y << 16 | min x, height << 16 | width, -, -}; an empty box has width = height = 0.
+__global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int nsegs) {
+  const int seg = blockIdx.x, lane = threadIdx.x;
+  const int xcd = (int)(((long)(seg >> 2) * MSDA_XCDS) / (nsegs >> 2));     // image-major: the mapping of the sampling kernels
+  const int4* bb = ws.bbox + (long)seg * ntiles;
+  int4* list = ws.runs + (long)xcd * ws.runs_cap * 2;
+  const MvBox none{32767, 32767, -32768, -32768};
+  int t0 = 0, nrows = 0, npass = 0;
+  MvBox c0 = none, c1 = none;                                               // current run: union boxes of the two point groups (uniform)
+  auto emit = [&](int t1) {
+    const int k0 = mv_rows(c0), k1 = mv_rows(c1);
+    if (k0 + k1 > 0 && t1 > t0) {
+      nrows += k0 + k1;
+      npass += (t1 - t0) * ((k0 + k1 + MV_CAP - 1) / MV_CAP);
+      if (lane == 0) {
+        const int slot = atomicAdd(ws.ctrl + xcd, 1);
+        const bool s0 = k0 > 0, s1 = k1 > 0;
+        list[2 * slot] = make_int4(seg, t0 | ((t1 - t0) << 24), s0 ? (c0.y0 << 16) | (c0.x0 & 0xffff) : 0,
+                                   s0 ? ((c0.y1 - c0.y0 + 1) << 16) | (c0.x1 - c0.x0 + 1) : 0);
+        list[2 * slot + 1] = make_int4(s1 ? (c1.y0 << 16) | (c1.x0 & 0xffff) : 0, s1 ? ((c1.y1 - c1.y0 + 1) << 16) | (c1.x1 - c1.x0 + 1) : 0, 0, 0);
+      }
+    }
+  };
+  for (int base = 0; base < ntiles; base += 64) {
+    const int4 v = base + lane < ntiles ? bb[base + lane] : make_int4(MV_EMPTY_MIN, MV_EMPTY_MAX, MV_EMPTY_MIN, MV_EMPTY_MAX);
+    const int n = min(64, ntiles - base);
+    for (int j = 0; j < n; ++j) {
+      const MvBox b0 = mv_unpack(__builtin_amdgcn_readlane(v.x, j), __builtin_amdgcn_readlane(v.y, j));
+      const MvBox b1 = mv_unpack(__builtin_amdgcn_readlane(v.z, j), __builtin_amdgcn_readlane(v.w, j));
+      const MvBox n0 = mv_join(c0, b0), n1 = mv_join(c1, b1);
+      const int t = base + j;
+      if (t > t0 && (mv_rows(n0) + mv_rows(n1) > MV_CAP || t - t0 >= MV_RMAX)) {
+        emit(t);
+        t0 = t; c0 = mv_some(b0) ? b0 : none; c1 = mv_some(b1) ? b1 : none;
+      } else { c0 = n0; c1 = n1; }
+    }
+  }
+  emit(ntiles);
+  if (lane == 0 && nrows) { atomicAdd(ws.ctrl + 16, nrows); atomicAdd(ws.ctrl + 17, npass); }
+}
+
+struct MvArgs {
+  MmArgs f;                                   // forward inputs (value / out / loc_out / attw_out unused)
+  const bf16_t* gout;                         // (B, Nq, nH*64)
+  float* d_value;                             // (B, Nv, nH, 64) f32, accumulated into
+  MvWs ws;
+};
+
+// raw projections of one lane's 4 points of a tile: offsets of the run's level (16 B), logits of all four levels (4 x 8 B), reference point
+struct MvRaw { uint4 o; uint2 l0, l1, l2, l3; float rx, ry; };
+__device__ __forceinline__ MvRaw mv_load_raw(const MmArgs& a, int b, int head, int lvl, int g, int qq) {
+  const long row = (long)b * a.Nq + qq;
+  MvRaw r;
+  r.o = *(const uint4*)(a.off + row * a.off_ld + head * 64 + lvl * 16 + g * 8);
+  const bf16_t* lp = a.logit + row * a.logit_ld + head * 32 + g * 4;
+  r.l0 = *(const uint2*)lp; r.l1 = *(const uint2*)(lp + 8); r.l2 = *(const uint2*)(lp + 16); r.l3 = *(const uint2*)(lp + 24);
+  const float* rp = a.ref + (long)b * a.ref_sb + (long)qq * a.ref_sq + (long)lvl * a.ref_sl;
+  r.rx = rp[0]; r.ry = rp[1];
+  return r;
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVES, MM_WAVES))) msda_mm_bwd_v_k(MvArgs va) {
+  __shared__ __attribute__((aligned(16))) bf16_t cimg[MV_CIMG];
+  __shared__ __attribute__((aligned(16))) bf16_t stage[2 * MV_HALF];
+  const MmArgs& a = va.f;
+  const int nh64 = a.nH * 64;
+  const int xcd = blockIdx.x % MSDA_XCDS;
+  const int nrun = va.ws.ctrl[xcd];
+  const int4* list = va.ws.runs + (long)xcd * va.ws.runs_cap * 2;
+  int* cursor = va.ws.ctrl + MSDA_XCDS + xcd;
+  for (;;) {
+    int it = 0;
+    if (threadIdx.x == 0) it = atomicAdd(cursor, 1);
+    it = __builtin_amdgcn_readfirstlane(it);
+    if (it >= nrun) break;
+    const int4 rec = list[2 * it], rec1 = list[2 * it + 1];
+    const int seg = __builtin_amdgcn_readfirstlane(rec.x), tt = __builtin_amdgcn_readfirstlane(rec.y);
+    const int min0 = __builtin_amdgcn_readfirstlane(rec.z), dim0 = __builtin_amdgcn_readfirstlane(rec.w);
+    const int min1 = __builtin_amdgcn_readfirstlane(rec1.x), dim1 = __builtin_amdgcn_readfirstlane(rec1.y);
+    const int lvl = seg & 3, bh = seg >> 2, head = bh % a.nH, b = bh / a.nH;
+    const int t0 = tt & 0xffffff, nt = (int)((unsigned)tt >> 24);
+    const int K0 = (dim0 & 0xffff) * (dim0 >> 16), Ks = K0 + (dim1 & 0xffff) * (dim1 >> 16);
+    const int Wl = a.lv.W[lvl], Hl = a.lv.H[lvl], lstart = a.lv.start[lvl];
+    const float fW = (float)Wl, fH = (float)Hl, rW = 1.f / fW, rH = 1.f / fH;
+    int lane0 = threadIdx.x;
+    asm volatile("" : "+v"(lane0));
+    // this lane's group: box and first row in the concatenated window
+    const int g = lane0 >> 5;
+    const int gmin = g ? min1 : min0, gdim = g ? dim1 : dim0;
+    const int xmin = (short)(gmin & 0xffff), ymin = gmin >> 16, bw = gdim & 0xffff, bhh = gdim >> 16, kofs = g ? K0 : 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < Ks; c0 += MV_CAP) {
+      const int rows = min(MV_CAP, Ks - c0);
+      const int nb = (rows + 31) >> 5;
+      mm_f32x16 acc[MV_NB][2];
+#pragma unroll
+      for (int i = 0; i < MV_NB; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; }
+      // software pipeline over the tiles of the run: order entry two tiles ahead, raw projections one tile ahead
+      const int qlast = a.Nq - 1;
+      auto order_of = [&](int tile, int q) { const int qi = min(tile * 32 + q, qlast); return a.order ? a.order[qi] : qi; };
+      int qq_cur = order_of(t0, lane0 & 31);
+      int qq_nxt = order_of(min(t0 + 1, t0 + nt - 1), lane0 & 31);
+      MvRaw raw_cur = mv_load_raw(a, b, head, lvl, g, qq_cur);
+#pragma unroll 1
+      for (int tile = t0; tile < t0 + nt; ++tile) {
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));                                      // see msda_mm_fwd_k
+        const int q = lane & 31;
+        const int tr_row = (lane >> 5) * 8 + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+        const bool qok = tile * 32 + q < a.Nq;
+        const int qq = qq_cur;
+        const MvRaw rw = raw_cur;
+        // the tile's 32 gradient rows -> LDS (2 x 16 rows x 2 channel halves); the previous tile's fragment reads have been consumed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int qr = __shfl(qq, j * 16 + (lane >> 2), 64);
+          const bf16_t* src = va.gout + ((long)b * a.Nq + qr) * nh64 + head * 64 + (lane & 3) * 8;
+          if (!(MV_DIAG & 1)) {
+            __builtin_amdgcn_global_load_lds(src, MM_LDS_PTR(void, stage + j * 16 * 32), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + 32, MM_LDS_PTR(void, stage + MV_HALF + j * 16 * 32), 16, 0, 0);
+          }
+        }
+        // in flight under this tile's arithmetic: the next tile's raw projections, the order entry of the tile after it
+        const bool more = tile + 1 < t0 + nt;
+        raw_cur = mv_load_raw(a, b, head, lvl, g, more ? qq_nxt : qq);
+        qq_cur = qq_nxt;
+        qq_nxt = order_of(min(tile + 2, t0 + nt - 1), q);
+        float aw[4];
+        {
+          const uint32_t u[8] = {rw.l0.x, rw.l0.y, rw.l1.x, rw.l1.y, rw.l2.x, rw.l2.y, rw.l3.x, rw.l3.y};
+          float e[16], m = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { e[2 * i] = __uint_as_float(u[i] << 16); e[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+#pragma unroll
+          for (int i = 0; i < 16; ++i) m = fmaxf(m, e[i]);
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          float sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { e[i] = __expf(e[i] - m); sum += e[i]; }
+          sum += __shfl_xor(sum, 32, 64);
+          const float inv = qok ? 1.f / sum : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) aw[i] = (lvl == 0 ? e[i] : lvl == 1 ? e[4 + i] : lvl == 2 ? e[8 + i] : e[12 + i]) * inv;
+        }
+        // taps (the arithmetic of mm_taps / msda_mm_bwd_lw_k to the bit: the run's boxes were computed from it)
+        int pk[4];
+        mm_f16x2 wt[4], wb[4];
+        {
+          const uint32_t u[4] = {rw.o.x, rw.o.y, rw.o.z, rw.o.w};
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float ox = __uint_as_float(u[p] << 16), oy = __uint_as_float(u[p] & 0xffff0000u);
+            const float lx = rw.rx + mm_div(ox, fW, rW), ly = rw.ry + mm_div(oy, fH, rH);
+            const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+            const bool in = qok && y > -1.f && x > -1.f && y < fH && x < fW;
+            const float xc = fminf(fmaxf(x, -1.f), fW), yc = fminf(fmaxf(y, -1.f), fH);
+            const float xf = floorf(xc), yf = floorf(yc);
+            const int x0 = (int)xf, y0 = (int)yf;
+            const float ax = xc - xf, ay = yc - yf;
+            const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+            const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+            // a tap outside the group's box cannot happen when the box comes from the same arithmetic; a foreign workspace must not corrupt memory
+            const bool live = in && xa >= xmin && xb < xmin + bw && ya >= ymin && yb < ymin + bhh;
+            const float wgt = live ? aw[p] : 0.f;
+            const float wxa = x0 >= 0 ? (1.f - ax) * wgt : 0.f, wxb = x0 + 1 < Wl ? ax * wgt : 0.f;
+            const float wya = y0 >= 0 ? 1.f - ay : 0.f, wyb = y0 + 1 < Hl ? ay : 0.f;
+            wt[p] = __builtin_bit_cast(mm_f16x2, __builtin_amdgcn_cvt_pkrtz(wya * wxa, wya * wxb));
+            wb[p] = __builtin_bit_cast(mm_f16x2, __builtin_amdgcn_cvt_pkrtz(wyb * wxa, wyb * wxb));
+            const int r00 = mul24(ya - ymin, bw) + (xa - xmin) + kofs;
+            pk[p] = live ? (r00 | ((xb - xa) << 30) | ((yb - ya) << 31)) : 0;       // r00 < 2^24 (two boxes of msda_levels' < 2^23 maps)
+          }
+        }
+        // clear the row blocks in use (2.5 KB each), then drop the coefficients
+        if (!(MV_DIAG & 16)) {
+          const uint4 z = make_uint4(0, 0, 0, 0);
+          for (int i = lane * 8; i < nb * 32 * MV_CROW; i += 512) *(uint4*)(cimg + i) = z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        bf16_t* ccol = cimg + q;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (MV_DIAG & 2) break;
+          const int k = pk[p];
+          const int r00 = (k & 0x3fffffff) - c0, dx = (k >> 30) & 1;
+          const int r10 = r00 + ((k >> 31) & bw);
+          const float w00 = (float)wt[p][0], w01 = (float)wt[p][1], w10 = (float)wb[p][0], w11 = (float)wb[p][1];
+          const bool o00 = (unsigned)r00 < (unsigned)MV_CAP && w00 != 0.f, o01 = (unsigned)(r00 + dx) < (unsigned)MV_CAP && w01 != 0.f;
+          const bool o10 = (unsigned)r10 < (unsigned)MV_CAP && w10 != 0.f, o11 = (unsigned)(r10 + dx) < (unsigned)MV_CAP && w11 != 0.f;
+          if (__builtin_amdgcn_ballot_w64(o00 || o01 || o10 || o11) == 0) continue;
+          const int i00 = (o00 ? r00 : MV_CAP) * MV_CROW, i01 = (o01 ? r00 + dx : MV_CAP + 1) * MV_CROW;
+          const int i10 = (o10 ? r10 : MV_CAP + 2) * MV_CROW, i11 = (o11 ? r10 + dx : MV_CAP + 3) * MV_CROW;
+          const float v00 = bf2f(ccol[i00]) + w00, v01 = bf2f(ccol[i01]) + w01, v10 = bf2f(ccol[i10]) + w10, v11 = bf2f(ccol[i11]) + w11;
+          ccol[i00] = mm_bf(v00); ccol[i01] = mm_bf(v01); ccol[i10] = mm_bf(v10); ccol[i11] = mm_bf(v11);
+        }
+        // the two lanes of a query write different ROWS (their groups' boxes), but a masked corner of group 0 and one of group 1 share
+        // the dump rows: harmless (never read)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // gradient rows have landed (and the prefetches), image complete
+        __builtin_amdgcn_wave_barrier();
+        mm_bf16x8 Bf[2][2];                                                 // queries ks * 16 .. + 15 of both channel halves
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const bf16_t* p = stage + half * MV_HALF + (ks * 16 + tr_row) * 32 + tr_col;
+            const mm_bf16x4 u0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, p));
+            const mm_bf16x4 u1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, p + 4 * 32));
+            Bf[ks][half] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+        for (int rb = 0; rb < MV_NB; ++rb) {
+          if (rb < nb && !(MV_DIAG & 4)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const mm_bf16x8 A = *(const mm_bf16x8*)(cimg + (rb * 32 + q) * MV_CROW + ks * 16 + (lane >> 5) * 8);
+              acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf[ks][0], acc[rb][0], 0, 0, 0);
+              acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf[ks][1], acc[rb][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // flush: C/D layout column = lane & 31 (channel of the half), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the block.  A row no
+      // point touched holds exact zeros: its lanes sit the atomic out (the atomic units are the bound: ~2 cycles per active lane and CU)
+      {
+        const int lane = threadIdx.x;
+        float* dvb = va.d_value + ((long)b * a.Nv * a.nH + head) * 64 + (lane & 31);
+        const int bw0 = dim0 & 0xffff, bw1 = dim1 & 0xffff;
+        const float ibw0 = 1.f / (float)max(bw0, 1), ibw1 = 1.f / (float)max(bw1, 1);
+        const int x00 = (short)(min0 & 0xffff), y00 = min0 >> 16, x01 = (short)(min1 & 0xffff), y01 = min1 >> 16;
+#pragma unroll
+        for (int rb = 0; rb < MV_NB; ++rb) {
+          if (rb < nb && !(MV_DIAG & 8)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const float v0 = acc[rb][0][r], v1 = acc[rb][1][r];
+              if (m < rows && (v0 != 0.f || v1 != 0.f)) {
+                const int wr = c0 + m;
+                const bool g1 = wr >= K0;
+                const int t = g1 ? wr - K0 : wr, bwg = g1 ? bw1 : bw0;
+                const int wy = (int)(((float)t + 0.5f) * (g1 ? ibw1 : ibw0));
+                const int wx = t - mul24(wy, bwg);
+                const int pix = mul24((g1 ? y01 : y00) + wy, Wl) + (g1 ? x01 : x00) + wx + lstart;
+                float* dst = dvb + (long)pix * nh64;
+                if (v0 != 0.f) atomicAdd(dst, v0);
+                if (v1 != 0.f) atomicAdd(dst + 32, v1);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+extern "C" size_t ge_msda_bwd_mm_workspace(int B, int Nq, int nH, int L) {
+  if (B <= 0 || Nq <= 0 || nH <= 0 || L != 4) return 0;
+  return mv_ws_layout(B, Nq, nH, nullptr, nullptr);
+}
+
+// Byte offset, inside the workspace, of the two ints the run cutter leaves behind: {window rows flushed, tile passes} of the latest
+// ge_msda_bwd_value_mm on that workspace — what its cost is made of (~0.28 ns per row + ~2.1 ns per pass on MI355X), so that a caller can
+// choose between it and the record pipeline, whose cost does not depend on the geometry.
+extern "C" size_t ge_msda_bwd_mm_stats_offset(int B, int Nq, int nH, int L) {
+  if (B <= 0 || Nq <= 0 || nH <= 0 || L != 4) return 0;
+  size_t o_ctrl = 0;
+  mv_ws_layout(B, Nq, nH, nullptr, nullptr, &o_ctrl);
+  return o_ctrl + 16 * sizeof(int);
+}
+
+// d_value of ge_msda_fwd_mm (accumulated into the zero-filled f32 tensor) from the gradient of the output.  `workspace` must be the one
+// ge_msda_bwd_lw_mm was given for the same inputs: its head holds the per-tile tap boxes that kernel leaves behind.
+extern "C" int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                                    const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out,
+                                    float* d_value, void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P,
+                                    int dtype, void* stream) {
+  if (!spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !workspace || B < 0 || Nq < 0) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  if (!msda_mm_supported(B, Nq, Nv, nH, L, P, dtype, lv)) return GE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)off_raw | (uintptr_t)logit_raw | (uintptr_t)d_out) & 15) || off_ld % 8 || logit_ld % 8) return GE_ERR_BAD_ARG;
+  if (B == 0 || Nq == 0) return GE_OK;
+  MvArgs va;
+  if (workspace_bytes < mv_ws_layout(B, Nq, nH, (char*)workspace, &va.ws)) return GE_ERR_BAD_ARG;
+  MmArgs& a = va.f;
+  a.value = nullptr; a.lv = lv;
+  a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
+  a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
+  a.out = nullptr; a.loc_out = nullptr; a.attw_out = nullptr;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = (Nq + 31) / 32;
+  va.gout = (const bf16_t*)d_out; va.d_value = d_value;
+  hipStream_t s = ge_stream(stream);
+  hipError_t he = hipMemsetAsync(va.ws.ctrl, 0, 32 * sizeof(int), s);
+  if (he != hipSuccess) return (int)he;
+  const int nsegs = B * nH * 4;
+  msda_mm_runs_k<<<(unsigned)nsegs, 64, 0, s>>>(va.ws, a.ntiles, nsegs);
+  GE_LAUNCH_CHECK();
+  if (!d_value) return GE_OK;                   // statistics only (ge_msda_bwd_mm_stats_offset)
+  static int per_cu = 0, n_cu = 0;
+  if (!per_cu) {
+    int dev = 0, v = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return GE_ERR_UNSUPPORTED;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, msda_mm_bwd_v_k, 64, 0) != hipSuccess || v < 1) v = 8;
+    n_cu = pr.multiProcessorCount; per_cu = v;
+  }
+  const long blocks = std::max((long)n_cu * per_cu / MSDA_XCDS * MSDA_XCDS, (long)MSDA_XCDS);
+  msda_mm_bwd_v_k<<<(unsigned)blocks, 64, 0, s>>>(va);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
 }

@@ -451,6 +451,58 @@ def msda_fwd_mm(value, raw, ref, spatial_shapes, order=None, want_loc=False, nH=
     return (out, loc, attw) if want_loc else out
 
 
+class _MMValueChoice:
+    """Which d_value kernel the MFMA deformable attention uses for one problem shape.  The transposed-contraction kernel
+    (ge_msda_bwd_value_mm) costs ~2.1 ns per tile pass + ~0.28 ns per flushed window row (MI355X, tools/ubench/msda_mm/dv_time.py): 2.7 ms
+    at the KITTI shape with the reference points of an initialised model (runs of ~17 tiles share a window), 10 ms when every 32-query
+    tile has a window of its own; the record pipeline (ge_msda_bwd_value_raw) costs ~0.70 ns per (query, head) whatever the geometry
+    (4.4 ms).  The run cutter leaves {rows, passes} in the workspace; they are copied to pinned host memory asynchronously and read by a
+    LATER call (never a synchronisation), so the choice follows the geometry with a lag of a step.  GE_MSDA_VALUE=mm|records pins it."""
+    NS_PASS, NS_ROW, NS_QH = 2.1, 0.28, 0.70
+    EVERY = 16                                        # steady state: look at the statistics every 16th call
+
+    def __init__(self):
+        self.use_mm, self.calls, self.pending, self.last = True, 0, None, None
+        self.forced = {'mm': True, 'records': False}.get(os.environ.get('GE_MSDA_VALUE', ''))
+
+    def wants_stats(self):
+        return self.forced is None and (self.calls <= 4 or self.calls % self.EVERY == 0) and not torch.cuda.is_current_stream_capturing()
+
+    def observe(self, ws, offset, n_qh):
+        if self.forced is not None or torch.cuda.is_current_stream_capturing() or not self.wants_stats() or self.pending is not None:
+            return
+        host = torch.empty(2, dtype=torch.int32).pin_memory()
+        host.copy_(ws[offset:offset + 8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (host, ev, n_qh)
+
+    def update(self):
+        self.calls += 1
+        if self.pending is not None and self.pending[1].query():
+            host, _, n_qh = self.pending
+            rows, passes = int(host[0]), int(host[1])
+            self.pending = None
+            if passes > 0:
+                t_mm, t_rec = self.NS_PASS * passes + self.NS_ROW * rows, self.NS_QH * n_qh
+                self.last = dict(rows=rows, passes=passes, mm_ms=t_mm * 1e-6, records_ms=t_rec * 1e-6)
+                # hysteresis: change only for a 10 % predicted gain
+                self.use_mm = t_mm < 0.9 * t_rec if not self.use_mm else t_mm < 1.1 * t_rec
+
+
+_MM_VALUE_CHOICE = {}
+
+
+def _mm_value_choice(key, mm_ok, rec_ok):
+    c = _MM_VALUE_CHOICE.get(key)
+    if c is None:
+        c = _MM_VALUE_CHOICE[key] = _MMValueChoice()
+    c.update()
+    use = c.use_mm if c.forced is None else c.forced
+    use = False if not mm_ok else True if not rec_ok else use          # only one of the two covers this call: no choice to make
+    return c, use
+
+
 class _MSDeformAttnMM(torch.autograd.Function):
     """Deformable attention from the raw projections on the MFMA decomposition (csrc/msda_mm.hip): forward ge_msda_fwd_mm, backward
     ge_msda_bwd_lw_mm (d_raw) + ge_msda_dref (d_ref) + the binned d_value scatter (ge_msda_bwd_value)."""
@@ -480,27 +532,49 @@ class _MSDeformAttnMM(torch.autograd.Function):
         d_raw = torch.empty(B, Nq, ld, device=value.device, dtype=raw.dtype)
         base, dbase = hip.ptr(raw), hip.ptr(d_raw)
         nb_lw = value.numel() * 2 + raw.numel() * 2 + d_raw.numel() * 2 + d_out.numel() * 2
+        # round 5: d_value as the transposed contraction dV_window = C^T dO (ge_msda_bwd_value_mm); the d_raw kernel leaves the per-tile
+        # tap boxes in the shared workspace.  Its cost depends on the geometry (how compact the windows of consecutive query tiles are), the
+        # record pipeline's (ge_msda_bwd_value_raw) does not: _mm_value_choice picks per call from the run statistics of earlier calls
+        want_dv = ctx.needs_input_grad[0]
+        mm_ws_bytes = int(lib.ge_msda_bwd_mm_workspace(B, Nq, nH, L)) if (want_dv and 'msda_value_mm' not in DISABLED) else 0
+        mm_ws = torch.empty(mm_ws_bytes, device=value.device, dtype=torch.uint8) if mm_ws_bytes else None
         PROFILER.run(f'msda_mm_bwd_lw_k[B{B} Nq{Nq} Nv{Nv}]', nb_lw, lambda: hip.check(lib.ge_msda_bwd_lw_mm(
             hip.ptr(value), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
-            hip.ptr(order), hip.ptr(d_out), dbase, ld, dbase + n_off * 2, ld, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
-            'ge_msda_bwd_lw_mm'))
+            hip.ptr(order), hip.ptr(d_out), dbase, ld, dbase + n_off * 2, ld, hip.ptr(mm_ws), B, Nv, Nq, nH, L, P, hip.dtype_code(value),
+            hip.stream()), 'ge_msda_bwd_lw_mm'))
         d_ref = None
         if ctx.needs_input_grad[2]:
             d_ref = torch.empty(B, Nq, L, 2, device=value.device, dtype=_f32)
             hip.check(lib.ge_msda_dref(dbase, ld, shapes_p, hip.ptr(d_ref), B * Nq, nH, L, P, hip.dtype_code(value), hip.stream()), 'ge_msda_dref')
         d_value = None
-        if ctx.needs_input_grad[0]:
+        if want_dv:
             d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
-            ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
-            assert ws_bytes > 0, 'binned d_value path unavailable for this geometry'
-            ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8)
-            if PROFILER.on:       # algorithmic bytes per stage: count reads the offsets, fill offsets + logits, drain d_out + d_value
-                PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, d_out.numel() * 2 + d_value.numel() * 4))
-            PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}]', B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
-                         lambda: hip.check(lib.ge_msda_bwd_value_raw(
-                             shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
-                             hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value),
-                             hip.stream()), 'ge_msda_bwd_value_raw'))
+            rec_ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
+            choice, use_mm = _mm_value_choice((B, Nq, Nv, nH, shapes, str(value.device)), mm_ws is not None, rec_ws_bytes > 0)
+
+            def value_mm(dv):
+                return hip.check(lib.ge_msda_bwd_value_mm(
+                    shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(order),
+                    hip.ptr(d_out), hip.ptr(dv), hip.ptr(mm_ws), mm_ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
+                    'ge_msda_bwd_value_mm')
+            if use_mm:
+                # algorithmic bytes: the raw projections + d_out read once, d_value written once
+                PROFILER.run(f'msda_mm_bwd_v_k[B{B} Nq{Nq} Nv{Nv}]', raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4, lambda: value_mm(d_value))
+            else:
+                if rec_ws_bytes <= 0:
+                    raise RuntimeError('ms_deform_attn_mm backward: neither the MFMA d_value kernel nor the binned path covers this geometry')
+                if mm_ws is not None and choice.wants_stats():
+                    value_mm(None)                  # run statistics only (~50 us): keeps the choice informed while the record path runs
+                ws = torch.empty(rec_ws_bytes, device=value.device, dtype=torch.uint8)
+                if PROFILER.on:       # algorithmic bytes per stage: count reads the offsets, fill offsets + logits, drain d_out + d_value
+                    PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, d_out.numel() * 2 + d_value.numel() * 4))
+                PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}]', B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
+                             lambda: hip.check(lib.ge_msda_bwd_value_raw(
+                                 shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+                                 hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), rec_ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value),
+                                 hip.stream()), 'ge_msda_bwd_value_raw'))
+            if mm_ws is not None:
+                choice.observe(mm_ws, int(lib.ge_msda_bwd_mm_stats_offset(B, Nq, nH, L)), B * Nq * nH)
             d_value = d_value.to(value.dtype)
         return d_value, d_raw, d_ref, None, None, None, None, None
 

@@ -36,7 +36,8 @@ enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
 
 /* Library / device identification: returns the ABI version (3: round 3 added the raw-projection deformable-attention entry points,
  * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline; 4: round 4 added the MFMA
- * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw), the token GEMM ge_gemm_nt and ge_conv1x1_nhwc_wgrad). */
+ * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw), the token GEMM ge_gemm_nt and ge_conv1x1_nhwc_wgrad;
+ * 5: round 5 — ge_msda_bwd_lw_mm takes a workspace, ge_msda_bwd_value_mm / ge_msda_bwd_mm_workspace added). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -189,8 +190,23 @@ int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const void* off_raw
  * d_value f32 zero-filled by the caller); ge_msda_dref rebuilds d_ref (rows, L, 2) f32 from the emitted d_off_raw. */
 int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
                       const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, void* d_off_raw,
-                      long d_off_ld, void* d_logit_raw, long d_logit_ld, int B, int Nv, int Nq, int nH, int L, int P, int dtype,
-                      void* stream);
+                      long d_off_ld, void* d_logit_raw, long d_logit_ld, void* workspace, int B, int Nv, int Nq, int nH, int L, int P,
+                      int dtype, void* stream);
+/* d_value of ge_msda_fwd_mm as the transpose of the forward contraction (round 5, ABI 5; csrc/msda_mm.hip: dV_window = C^T dO on the
+ * matrix cores, one fp32 atomic flush per RUN of consecutive query tiles that share a window).  Replaces mmcv's
+ * ms_deformable_col2im (atomicAdd into grad_value) as called from depth/models/necks/hahi.py:316-325, and the count / scan / fill /
+ * drain record pipeline of ge_msda_bwd_value_raw for the cross-attention.  d_value (B, Nv, nH, 64) f32 is ACCUMULATED into
+ * (zero-fill it first).  `workspace` (>= ge_msda_bwd_mm_workspace(B, Nq, nH, L) bytes, 0 = unsupported) is shared with
+ * ge_msda_bwd_lw_mm: that call — same inputs, same `order`, earlier on the same stream — leaves the per-tile tap boxes in it
+ * (its `workspace` argument may be NULL when no ge_msda_bwd_value_mm follows).  The kernel's cost depends on how compact the windows of
+ * consecutive query tiles are; d_value == NULL only cuts the runs and leaves two ints {window rows to flush, tile passes} at byte
+ * ge_msda_bwd_mm_stats_offset(...) of the workspace (they are also written by a full call), from which a caller can decide between this
+ * entry point and ge_msda_bwd_value_raw, whose cost is independent of the geometry. */
+size_t ge_msda_bwd_mm_workspace(int B, int Nq, int nH, int L);
+size_t ge_msda_bwd_mm_stats_offset(int B, int Nq, int nH, int L);
+int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
+                         long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, float* d_value, void* workspace,
+                         size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 int ge_msda_bwd_value(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out, float* d_value,
                       void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 /* ge_msda_bwd_value fed from the raw projections instead of loc / attw (bf16, L == 4, P == 8; 8-byte records): with it the forward
