@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 from gedepth_amd.depth.utils.position_encoding import SinePositionalEncoding
 from gedepth_amd import kernels as K
 torch.manual_seed(1234)
-pe = SinePositionalEncoding(num_feats=256, normalize=True)
+pe = SinePositionalEncoding(num_feats=256, normalize=False)     # the configs' encoding (round 4 had normalize=True here: a far more concentrated geometry than the model's)
 pos = pe.grid(176, 560, 'cpu')
 lin = torch.nn.Linear(512, 2); torch.nn.init.xavier_uniform_(lin.weight); torch.nn.init.constant_(lin.bias, 0.)
 ref = torch.sigmoid(lin(pos.flatten(2)[0].t())).detach()

@@ -16,11 +16,16 @@ B, nq = 8, 176 * 560
 nv = sum(h * w for h, w in KS)
 g = torch.Generator().manual_seed(1)
 torch.manual_seed(1234)
-pe = SinePositionalEncoding(num_feats=256, normalize=True)
+# geometry: 'model' (default) = the bench model at initialisation: sigmoid(Linear(sine embedding)) with the configs' un-normalised sine
+# embedding (hahi.py:294-302): reference points over half of the level-0 cells, ~8 queries per cell, a 32-query tile spans ~4 x 3 cells;
+# 'concentrated' = the same with normalize=True (what tools/ubench/msda_mm/dump_inputs.py fed the round-4 harness: all 98 560 reference
+# points inside 22 % x 27 % of the map, ~110 queries per cell — NOT the model's geometry); 'spread' = reference point = own position
+geom = sys.argv[1] if len(sys.argv) > 1 else 'model'
+pe = SinePositionalEncoding(num_feats=256, normalize=(geom == 'concentrated'))
 pos = pe.grid(176, 560, 'cpu')
 lin = torch.nn.Linear(512, 2); torch.nn.init.xavier_uniform_(lin.weight); torch.nn.init.constant_(lin.bias, 0.)
-spread = len(sys.argv) > 1 and sys.argv[1] == 'spread'
-if spread:      # reference point = the query's own position (what a trained model plausibly does): 4 queries per level-0 cell
+spread = geom == 'spread'
+if spread:
     gy, gx = torch.meshgrid((torch.arange(176) + 0.5) / 176, (torch.arange(560) + 0.5) / 560, indexing='ij')
     ref0 = torch.stack((gx.reshape(-1), gy.reshape(-1)), -1).to(dev)
 else:
@@ -42,7 +47,7 @@ for tag, dis in (('mfma d_value', set()), ('record pipeline', {'msda_value_mm'})
     K.PROFILER.enable()
     for _ in range(5): run()
     K.PROFILER.disable()
-    print(tag, '(spread reference points)' if spread else '(init-like reference points)')
+    print(tag, f'({geom} reference points)')
     for r in K.PROFILER.summary() + K.PROFILER.msda_bwd_stages():
         print(f'   {r["name"]:44s} {r["avg_us"]:9.1f} us')
     res[tag] = value.grad.float().clone()
