@@ -14,8 +14,13 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# ROCm 7.2: hipGraph replays that overlap host -> device copies on another stream faulted ("illegal memory access") with the runtime's
+# AQL-packet capture of graph kernels enabled; with it off the same runs are clean and equally fast (gedepth_amd/mmrt/graph.py).  The
+# runtime reads the variable when it starts, i.e. before the first import of torch.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,6 +43,11 @@ def parse():
     ap.add_argument('--bucket-mb', type=float, default=None, help='DDP bucket size in MiB (default 32)')
     ap.add_argument('--attn', default='auto', choices=['auto', 'fp8'],
                     help="window attention: 'fp8' = e4m3 MFMA forward contractions (BASELINE.json configs[4]); 'auto' = bf16 MFMA")
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='on: the step (forward + losses + backward + gradient exchange + clip + AdamW) is captured in a hipGraph after three eager '
+                         'steps and replayed with one launch (gedepth_amd/mmrt/graph.py); off: every kernel launched from Python; auto: on when '
+                         'the step is launch-bound (<= 4 images per GPU: 1700 - 2400 launches, ~1000 of them shorter than 10 us), off when the '
+                         'device is the bound anyway (8 images per GPU: 49.3 ms either way)')
     ap.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'],
                     help='nhwc: channels-last conv stack (depth.models.utils.to_channels_last): no MIOpen layout transposes, tokens <-> maps are views')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -144,7 +154,12 @@ def respawn_under_launcher(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def build_job(args, cfg, dev, rank, dtype):
+def kernels_profiler_on():
+    from gedepth_amd import kernels
+    return kernels.PROFILER.on
+
+
+def build_job(args, cfg, dev, rank, dtype, graph=True):
     """model + optimizer + DDP wrapper + resident synthetic batch + the step closure for one precision."""
     from gedepth_amd.depth.datasets.synthetic import synthetic_batch
     from gedepth_amd.depth.models import build_depther
@@ -154,6 +169,13 @@ def build_job(args, cfg, dev, rank, dtype):
     torch.manual_seed(1234)
     model = build_depther(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     model.init_weights()
+    nodrop = os.environ.get('GE_BENCH_NODROP', '')             # debugging aid: 1 = no stochastic depth and no attention dropout, path / attn = one of them off
+    if nodrop:
+        for m in model.modules():
+            if hasattr(m, 'drop_prob') and nodrop in ('1', 'path'):
+                m.drop_prob = 0.0
+            if isinstance(m, torch.nn.Dropout) and nodrop in ('1', 'attn'):
+                m.p = 0.0
     model = model.to(dev).train()
     if args.layout == 'nhwc':
         from gedepth_amd.depth.models.utils import to_channels_last
@@ -170,7 +192,7 @@ def build_job(args, cfg, dev, rank, dtype):
         batch['height'] = torch.full((per_gpu,), 1.56, device=dev)
     amp = dtype == 'bf16'
 
-    def step(b=None):
+    def eager_step(b=None):
         optimizer.zero_grad()
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
             out = ddp.train_step(batch if b is None else b, optimizer)
@@ -178,6 +200,18 @@ def build_job(args, cfg, dev, rank, dtype):
         ddp.finish()
         optimizer.step()
         return out
+    step = eager_step
+    if (args.graph == 'on' or (args.graph == 'auto' and per_gpu <= 4)) and graph:
+        from gedepth_amd.mmrt.graph import GraphedTrainStep
+        # the first 3 calls run eagerly (library kernel selection, DropPath bank, FlatDDP's arrival-order layout), the 4th captures
+        gstep = GraphedTrainStep(model, optimizer, batch, amp_dtype=torch.bfloat16 if amp else None, ddp=ddp, warmup=3)
+
+        def step(b=None):
+            if kernels_profiler_on():          # the per-kernel HIP-event pass needs individual launches
+                return eager_step(b)
+            return gstep(b)
+        step.graphed = gstep
+    step.eager = eager_step
     step.batch = batch
     step.ddp = ddp
     return step, per_gpu, optimizer
@@ -289,7 +323,7 @@ def main():
     ddp_info = step.ddp.describe()
     if ddp_info['active']:
         step.ddp.trace(True)
-        step()
+        step.eager()                                         # launched from Python: a graph replay runs no hooks, so there is nothing to stamp
         fence()
         step.ddp.trace(False)
         ddp_info['trace'] = [dict(bucket=r['bucket'], MB=round(r['bytes'] / 2 ** 20, 2), params=r['params'], launch_ms=round(r['launch_ms'], 3),
@@ -356,6 +390,12 @@ def main():
                 return row
             res['kernels'] = [krow(r) for r in sorted(prof + stages, key=lambda r: -r['total_ms'])[:24]]
             res['own_kernels_ms_per_step'] = round(prof_ms_per_step, 2)
+    graph_info = None
+    if getattr(step, 'graphed', None) is not None:
+        graph_info = dict(captured=step.graphed.graph is not None, replays=step.graphed.replays)
+        step.graphed.release()
+    if rank == 0:
+        res['config']['hip_graph'] = graph_info or 'off'
     del step, optimizer, out
     torch.cuda.empty_cache()
 
@@ -376,6 +416,8 @@ def main():
                            'steps': args.fp32_steps, 'warmup': 4, 'dtype': 'fp32', 'last_loss': round(float(o32['log_vars']['loss']), 5),
                            'note': 'same workload with fp32 storage and arithmetic everywhere (the reference\'s precision; exact-fp32 window attention, MIOpen '
                                    + ('find mode from the committed find-db)' if fp32_find else 'immediate mode)')}
+        if getattr(step32, 'graphed', None) is not None:
+            step32.graphed.release()
         del step32, opt32, o32
         torch.cuda.empty_cache()
     if rank == 0:

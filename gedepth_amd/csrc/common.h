@@ -74,6 +74,14 @@ __device__ __forceinline__ Lerp ge_lerp(int dst, int in, float scale, bool align
 }
 
 static inline hipStream_t ge_stream(void* s) { return (hipStream_t)s; }
+
+// Dropout masks are a counter-based hash of (seed, element index) with the seed a launch ARGUMENT — frozen when the launch is captured in a
+// hipGraph.  ge_rng_salt(ptr) (neck.hip) registers a device counter that every dropout kernel adds to its seed at EXECUTION time; a
+// captured step increments it inside the graph, so each replay draws fresh masks (forward and backward of one step read the same value).
+const unsigned long long* ge_rng_salt_get();
+__device__ __forceinline__ uint64_t ge_salted(uint64_t seed, const unsigned long long* salt) {
+  return salt ? seed + (uint64_t)*salt * 0x9E3779B97F4A7C15ull : seed;
+}
 static inline unsigned ge_blocks(long n, int per_block, long cap = 1 << 20) {
   long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;

@@ -25,7 +25,8 @@ __device__ __forceinline__ float ge_drop_scale(uint64_t seed, uint64_t idx, floa
 template <typename T, bool VEC, bool DROP>
 __global__ void __launch_bounds__(256) tokens_from_map_k(const T* __restrict__ map, long map_bs, const float* __restrict__ pos,
                                                          T* __restrict__ tok, long tok_bs, int C, long N, float p, float inv_keep,
-                                                         uint64_t seed) {
+                                                         uint64_t seed0, const unsigned long long* __restrict__ salt) {
+  const uint64_t seed = ge_salted(seed0, salt);
   constexpr int VN = V8<T>::N, LPR = NECK_TILE / VN, RPP = 256 / LPR;
   __shared__ float tile[NECK_TILE][NECK_TILE + 1];              // [c][n]
   const long n0 = (long)blockIdx.x * NECK_TILE;
@@ -89,7 +90,8 @@ __global__ void __launch_bounds__(256) tokens_from_map_k(const T* __restrict__ m
 template <typename T, bool VEC, bool DROP>
 __global__ void __launch_bounds__(256) map_from_tokens_k(const T* __restrict__ tok, long tok_bs, const T* __restrict__ res, long res_bs,
                                                          T* __restrict__ map, long map_bs, int C, long N, float p, float inv_keep,
-                                                         uint64_t seed) {
+                                                         uint64_t seed0, const unsigned long long* __restrict__ salt) {
+  const uint64_t seed = ge_salted(seed0, salt);
   constexpr int VN = V8<T>::N, LPR = NECK_TILE / VN, RPP = 256 / LPR;
   __shared__ float tile[NECK_TILE][NECK_TILE + 1];              // [c][n]
   const long n0 = (long)blockIdx.x * NECK_TILE;
@@ -149,6 +151,10 @@ __global__ void __launch_bounds__(256) map_from_tokens_k(const T* __restrict__ t
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+static const unsigned long long* g_rng_salt = nullptr;
+const unsigned long long* ge_rng_salt_get() { return g_rng_salt; }
+extern "C" int ge_rng_salt(const unsigned long long* device_counter) { g_rng_salt = device_counter; return GE_OK; }
+
 template <typename T>
 static int tokens_from_map_launch(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
                                   float p, uint64_t seed, hipStream_t s) {
@@ -157,7 +163,7 @@ static int tokens_from_map_launch(const void* map, long map_bs, const float* pos
   const bool drop = p > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - p) : 1.f;
   dim3 grid((unsigned)((N + NECK_TILE - 1) / NECK_TILE), (unsigned)((C + NECK_TILE - 1) / NECK_TILE), (unsigned)B);
-#define GE_TFM(V, D) tokens_from_map_k<T, V, D><<<grid, 256, 0, s>>>((const T*)map, map_bs, pos, (T*)tok, tok_bs, C, N, p, inv_keep, seed)
+#define GE_TFM(V, D) tokens_from_map_k<T, V, D><<<grid, 256, 0, s>>>((const T*)map, map_bs, pos, (T*)tok, tok_bs, C, N, p, inv_keep, seed, ge_rng_salt_get())
   if (vec) { if (drop) GE_TFM(true, true); else GE_TFM(true, false); }
   else { if (drop) GE_TFM(false, true); else GE_TFM(false, false); }
 #undef GE_TFM
@@ -173,7 +179,7 @@ static int map_from_tokens_launch(const void* tok, long tok_bs, const void* res,
   const bool drop = p > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - p) : 1.f;
   dim3 grid((unsigned)((N + NECK_TILE - 1) / NECK_TILE), (unsigned)((C + NECK_TILE - 1) / NECK_TILE), (unsigned)B);
-#define GE_MFT(V, D) map_from_tokens_k<T, V, D><<<grid, 256, 0, s>>>((const T*)tok, tok_bs, (const T*)res, res_bs, (T*)map, map_bs, C, N, p, inv_keep, seed)
+#define GE_MFT(V, D) map_from_tokens_k<T, V, D><<<grid, 256, 0, s>>>((const T*)tok, tok_bs, (const T*)res, res_bs, (T*)map, map_bs, C, N, p, inv_keep, seed, ge_rng_salt_get())
   if (vec) { if (drop) GE_MFT(true, true); else GE_MFT(true, false); }
   else { if (drop) GE_MFT(false, true); else GE_MFT(false, false); }
 #undef GE_MFT

@@ -592,7 +592,8 @@ __device__ __forceinline__ float nh_drop_scale(uint64_t seed, uint64_t idx, floa
 template <typename T>
 __global__ void __launch_bounds__(256) concat_rows_k(const T* __restrict__ a, long rpb, long a_bs, const T* __restrict__ res, const T* __restrict__ b,
                                                      T* __restrict__ out, long R, int Ca, int Cb, int off_a, int off_b, float p, float inv_keep,
-                                                     uint64_t seed) {
+                                                     uint64_t seed0, const unsigned long long* __restrict__ salt) {
+  const uint64_t seed = ge_salted(seed0, salt);
   constexpr int VN = V8<T>::N;
   const int la = Ca / VN, lb = b ? Cb / VN : 0, lt = la + lb, Co = Ca + Cb;
   const long total = R * lt;
@@ -625,7 +626,8 @@ __global__ void __launch_bounds__(256) concat_rows_k(const T* __restrict__ a, lo
 // backward of the first part: d_a[r, :] = d_out[r, off_a : off_a + Ca] * drop(r, c)  (dense (R, Ca) out of rows of Co)
 template <typename T>
 __global__ void __launch_bounds__(256) slice_rows_drop_k(const T* __restrict__ d_out, T* __restrict__ d_a, long R, int Ca, int Co, int off_a,
-                                                         float p, float inv_keep, uint64_t seed) {
+                                                         float p, float inv_keep, uint64_t seed0, const unsigned long long* __restrict__ salt) {
+  const uint64_t seed = ge_salted(seed0, salt);
   constexpr int VN = V8<T>::N;
   const int la = Ca / VN;
   const long total = R * la;
@@ -652,9 +654,9 @@ extern "C" int ge_concat_rows_fwd(const void* a, long rows_per_batch, long a_bat
   const long total = rows * ((Ca + Cb) / vn);
   hipStream_t s = ge_stream(stream);
   if (dtype == GE_F32)
-    concat_rows_k<float><<<nh_grid_vec(total), 256, 0, s>>>((const float*)a, rows_per_batch, a_batch_stride, (const float*)res, Cb ? (const float*)b : nullptr, (float*)out, rows, Ca, Cb, off_a, off_b, p_drop, inv_keep, seed);
+    concat_rows_k<float><<<nh_grid_vec(total), 256, 0, s>>>((const float*)a, rows_per_batch, a_batch_stride, (const float*)res, Cb ? (const float*)b : nullptr, (float*)out, rows, Ca, Cb, off_a, off_b, p_drop, inv_keep, seed, ge_rng_salt_get());
   else
-    concat_rows_k<bf16_t><<<nh_grid_vec(total), 256, 0, s>>>((const bf16_t*)a, rows_per_batch, a_batch_stride, (const bf16_t*)res, Cb ? (const bf16_t*)b : nullptr, (bf16_t*)out, rows, Ca, Cb, off_a, off_b, p_drop, inv_keep, seed);
+    concat_rows_k<bf16_t><<<nh_grid_vec(total), 256, 0, s>>>((const bf16_t*)a, rows_per_batch, a_batch_stride, (const bf16_t*)res, Cb ? (const bf16_t*)b : nullptr, (bf16_t*)out, rows, Ca, Cb, off_a, off_b, p_drop, inv_keep, seed, ge_rng_salt_get());
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
@@ -666,9 +668,9 @@ extern "C" int ge_slice_rows_drop(const void* d_out, void* d_a, long rows, int C
   const float inv_keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   hipStream_t s = ge_stream(stream);
   if (dtype == GE_F32)
-    slice_rows_drop_k<float><<<nh_grid_vec(rows * (Ca / vn)), 256, 0, s>>>((const float*)d_out, (float*)d_a, rows, Ca, Co, off_a, p_drop, inv_keep, seed);
+    slice_rows_drop_k<float><<<nh_grid_vec(rows * (Ca / vn)), 256, 0, s>>>((const float*)d_out, (float*)d_a, rows, Ca, Co, off_a, p_drop, inv_keep, seed, ge_rng_salt_get());
   else
-    slice_rows_drop_k<bf16_t><<<nh_grid_vec(rows * (Ca / vn)), 256, 0, s>>>((const bf16_t*)d_out, (bf16_t*)d_a, rows, Ca, Co, off_a, p_drop, inv_keep, seed);
+    slice_rows_drop_k<bf16_t><<<nh_grid_vec(rows * (Ca / vn)), 256, 0, s>>>((const bf16_t*)d_out, (bf16_t*)d_a, rows, Ca, Co, off_a, p_drop, inv_keep, seed, ge_rng_salt_get());
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -45,7 +45,7 @@ def train_depther(model, dataset, cfg, distributed=False, validate=False, timest
     logger(f'precision: {amp_name}' + (' (bf16 autocast, fp32 master weights)' if amp_name == 'bf16' else ' (reference precision)'))
     amp = torch.bfloat16 if amp_name == 'bf16' else None
     runner = IterBasedRunner(wrapped, optimizer, work_dir=cfg.get('work_dir'), logger=logger, meta=meta,
-                             max_iters=cfg.runner['max_iters'], amp_dtype=amp)
+                             max_iters=cfg.runner['max_iters'], amp_dtype=amp, hip_graph=bool(cfg.get('hip_graph', False)))
     runner.batch_transform = batch_transform
     if timestamp:
         runner.timestamp = timestamp

@@ -156,10 +156,15 @@ class HAHIHeteroNeck(BaseModule):
         slowly under training, so the sort (a dozen small launches) is redone only every ORDER_REFRESH forwards."""
         key = (tuple(ref_xy.shape), tuple(level0_hw), str(ref_xy.device))
         ent = self._order_cache.get(key)
-        if ent is None or ent[1] >= self.ORDER_REFRESH:
-            ent = [K.msda_ref_order(ref_xy.detach(), level0_hw), 0]
-            self._order_cache = {key: ent}
-        ent[1] += 1
+        # one entry per shape (train / validation / multi-scale shapes alternate without re-sorting); the reference points only move
+        # under training, so evaluation never refreshes, and a step being captured in a hipGraph keeps the order it has
+        stale = ent is not None and self.training and ent[1] >= self.ORDER_REFRESH and not torch.cuda.is_current_stream_capturing()
+        if ent is None or stale:
+            if len(self._order_cache) >= 8:
+                self._order_cache.clear()
+            ent = self._order_cache[key] = [K.msda_ref_order(ref_xy.detach(), level0_hw), 0]
+        if self.training:
+            ent[1] += 1
         return ent[0]
 
     def init_weights(self):

@@ -43,6 +43,7 @@ SIGNATURES = {
     'ge_msda_bwd_value': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_value_raw': (_i, [_vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_dref': (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    'ge_rng_salt': (_i, [_vp]),
     'ge_tokens_from_map': (_i, [_vp, _l, _vp, _vp, _l, _i, _i, _l, _f, _u64, _i, _vp]),
     'ge_map_from_tokens': (_i, [_vp, _l, _vp, _l, _vp, _l, _i, _i, _l, _f, _u64, _i, _vp]),
     'ge_bilinear_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

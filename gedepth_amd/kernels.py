@@ -479,6 +479,8 @@ class _MMValueChoice:
 
     def update(self):
         self.calls += 1
+        if torch.cuda.is_current_stream_capturing():      # a captured step keeps the choice it was captured with
+            return
         if self.pending is not None and self.pending[1].query():
             host, _, n_qh = self.pending
             rows, passes = int(host[0]), int(host[1])

@@ -520,7 +520,10 @@ class _DropPathBank:
             self.layers.append(weakref.ref(layer))
             self.rows = self.keep = None
         gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()] if device.type == 'cuda' else None
-        reseeded = gen is not None and (gen.initial_seed(), gen.get_offset() >= self.offset) != (self.seed, True)     # torch.manual_seed since the draw
+        # a step being captured in a hipGraph (mmrt/graph.py) may not query the generator; its refill is captured with torch's graph-safe
+        # Philox offsets, so every replay draws fresh rows
+        capturing = gen is not None and torch.cuda.is_current_stream_capturing()
+        reseeded = gen is not None and not capturing and (gen.initial_seed(), gen.get_offset() >= self.offset) != (self.seed, True)     # torch.manual_seed since the draw
         if self.rows is None or self.key != key or self.used[idx] or reseeded:
             probs = [1.0 - (r().drop_prob if r() is not None else 0.0) for r in self.layers]
             if self.keep is None or self.keep.device != device or probs != self.probs:
@@ -529,7 +532,7 @@ class _DropPathBank:
             self.rows = (self.keep + u).floor() / self.keep
             self.used = [False] * len(self.layers)
             self.key = key
-            if gen is not None:
+            if gen is not None and not capturing:
                 self.seed, self.offset = gen.initial_seed(), gen.get_offset()
         self.used[idx] = True
         return self.rows[idx]

@@ -231,8 +231,10 @@ class FusedAdamW(torch.optim.Optimizer):
         return self.gnorm_sq.sqrt()
 
     @torch.no_grad()
-    def step(self, closure=None):
-        assert closure is None
+    def prepare(self):
+        """Host half of a step: advance the step counter and put this step's scalars (lr, betas, eps, weight decay, bias corrections,
+        clip norm) into the device buffer the kernels read.  Kept apart from ``launch`` so that a captured training step
+        (gedepth_amd/mmrt/graph.py) holds only the kernels and the scalars are refreshed before every replay."""
         g0 = self.param_groups[0]
         assert all(g['lr'] == g0['lr'] for g in self.param_groups), 'per-group learning rates are not supported'
         self.step_count += 1
@@ -244,6 +246,10 @@ class FusedAdamW(torch.optim.Optimizer):
                                  self.max_grad_norm, 1 - b1, 1 - b2], dtype=torch.float32))      # 1 - beta in double, like torch
         self.hyper.copy_(host, non_blocking=True)
         ev.record()
+
+    @torch.no_grad()
+    def launch(self):
+        """Device half of a step: gradient norm + clip + AdamW (+ bf16 shadow) over the arenas.  Capturable."""
         lib, a = hip.lib(), self.arena
         a.collect()                            # gradients autograd handed over (not yet brought in by FlatDDP) -> arena
         self.gnorm_sq.zero_()
@@ -258,6 +264,12 @@ class FusedAdamW(torch.optim.Optimizer):
                                                hip.ptr(self.exp_avg_sq), hip.ptr(self.wd_mask), hip.ptr(self.hyper),
                                                hip.ptr(self.gnorm_sq), a.numel, hip.ptr(shadow), hip.stream()), 'ge_adamw_step_shadow')
             a.refresh_shadow(copy=False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self.prepare()
+        self.launch()
 
     def state_dict(self):
         """``torch.optim.AdamW`` layout (what mmcv's CheckpointHook stores and the reference's checkpoints hold):

@@ -60,6 +60,8 @@ class OptimizerHook(Hook):
         self.grad_clip = grad_clip
 
     def after_train_iter(self, runner):
+        if getattr(runner, 'graphed', None) is not None:       # backward, exchange and optimizer ran inside the captured step
+            return
         runner.outputs['loss'].backward()
         if hasattr(runner.model, 'finish'):
             runner.model.finish()
@@ -178,7 +180,11 @@ HOOKS = dict(TextLoggerHook=TextLoggerHook, TensorboardLoggerHook=TensorboardLog
 
 class IterBasedRunner:
 
-    def __init__(self, model, optimizer, work_dir=None, logger=print, meta=None, max_iters=None, amp_dtype=None):
+    def __init__(self, model, optimizer, work_dir=None, logger=print, meta=None, max_iters=None, amp_dtype=None, hip_graph=False):
+        """``hip_graph``: capture forward + losses + backward + gradient exchange + clip + AdamW in one hipGraph after three eager
+        iterations and replay it (mmrt/graph.py) — one launch per iteration instead of 1250 - 2400; needs batches of a fixed shape
+        (the reference's loaders use drop_last=True)."""
+        self.hip_graph, self.graphed = bool(hip_graph), None
         self.model, self.optimizer, self.work_dir, self.logger, self.meta = model, optimizer, work_dir, logger, meta or {}
         self.max_iters = max_iters
         self.iter = 0
@@ -253,6 +259,17 @@ class IterBasedRunner:
             # the batch dict; otherwise the collated host batch is staged with non-blocking copies
             batch = self.batch_transform(batch) if self.batch_transform is not None else self._to_device(batch, device)
             self.call_hook('before_train_iter')
+            if self.hip_graph:
+                if self.graphed is None:
+                    from .graph import GraphedTrainStep
+                    inner = self.model.module if hasattr(self.model, 'finish') else self.model
+                    static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+                    self.graphed = GraphedTrainStep(inner, self.optimizer, static, amp_dtype=self.amp_dtype,
+                                                    ddp=self.model if hasattr(self.model, 'finish') else None, warmup=3)
+                self.outputs = self.graphed(batch)
+                self.call_hook('after_train_iter')
+                self.iter += 1
+                continue
             self.optimizer.zero_grad()
             if self.amp_dtype is not None:
                 with torch.autocast(device.type, dtype=self.amp_dtype):

@@ -216,6 +216,12 @@ int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw, long off_l
                           size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 int ge_msda_dref(const void* d_off_raw, long off_ld, const int* spatial_hw, float* d_ref, long rows, int nH, int L, int P, int dtype,
                  void* stream);
+/* Dropout inside ge_tokens_from_map / ge_map_from_tokens / ge_concat_rows_fwd / ge_slice_rows_drop is a counter-based hash of (seed,
+ * element index); the seed is a launch argument, so a launch captured in a hipGraph would replay ONE mask for ever.  ge_rng_salt
+ * registers a device counter (NULL = none, the default) whose value, read when the kernel EXECUTES, is mixed into every seed: a captured
+ * training step increments it inside the graph (one more process-wide knob, like ge_msda_mode; forward and backward of a step must see the
+ * same value, i.e. increment it between steps only). */
+int ge_rng_salt(const unsigned long long* device_counter);
 int ge_tokens_from_map(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
                        float p_drop, unsigned long long seed, int dtype, void* stream);
 int ge_map_from_tokens(const void* tok, long tok_bs, const void* res, long res_bs, void* map, long map_bs, int B, int C,

@@ -717,3 +717,96 @@ def test_channels_last_model_matches_nchw(dev, amp):
     rel = ((ga - gb).double().norm() / gb.double().norm()).item()
     print(f'\n[channels-last vs NCHW, amp={amp}] losses {la} | gradient l2rel {rel:.2e}, cosine {cos:.6f}')
     assert rel <= (0.15 if amp else 2e-3) and cos >= (0.99 if amp else 0.999999), (rel, cos)
+
+
+def test_graphed_train_step_matches_eager_steps(dev):
+    """gedepth_amd/mmrt/graph.py: forward + losses + backward + clip + AdamW captured in ONE hipGraph and replayed must train like the
+    same steps launched from Python.  Two copies of the Adaptive model (stochastic depth and attention dropout off, so that both runs
+    are deterministic up to the order of fp32 atomics), the same four batches: one eager run, one run through GraphedTrainStep (1 eager
+    warm-up step, capture, 3 replays on batches COPIED into the static input buffers).  Losses of every step and the parameters after
+    the last one must agree; the optimizer's step counter (bias corrections) advances per replay; the dropout counter advances INSIDE
+    the graph (one per replay)."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.graph import GraphedTrainStep
+    from gedepth_amd.mmrt.optim import build_optimizer
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_a.py'))
+    batches = [synthetic_batch(2, 128, 160, seed=40 + i, device=dev, valid_fraction=0.3) for i in range(4)]
+
+    def make():
+        torch.manual_seed(0)
+        m = build('depthformer_swint_a.py', drop_path_rate=0.0)
+        m.neck.multi_att.dropout.p = 0.0
+        m.neck.self_attn.dropout.p = 0.0
+        load_filled(m, 'graph')
+        m = m.to(dev).train()
+        return m, build_optimizer(m, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    losses = {}
+    finals = {}
+    for mode in ('eager', 'graph'):
+        model, opt = make()
+        log = []
+        if mode == 'eager':
+            for b in batches:
+                opt.zero_grad()
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = model.train_step(b, opt)
+                out['loss'].backward()
+                opt.step()
+                log.append(dict(out['log_vars']))
+        else:
+            static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batches[0].items()}
+            gs = GraphedTrainStep(model, opt, static, amp_dtype=torch.bfloat16, warmup=1)
+            for b in batches:
+                out = gs(b)
+                log.append(dict(out['log_vars']))
+            assert gs.graph is not None and gs.replays == 3 and int(gs.salt.item()) == 3
+            assert opt.step_count == 4
+            gs.release()
+        torch.cuda.synchronize()
+        losses[mode] = log
+        finals[mode] = {n: p.detach().float().clone() for n, p in model.named_parameters()}
+    for i, (a, b) in enumerate(zip(losses['eager'], losses['graph'])):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (i, k, a[k], b[k])
+    # four AdamW steps at lr 1e-4: every element moves by about lr per step whatever the size of its gradient, so elements whose true
+    # gradient is zero (stage-norm biases in front of a training-mode BatchNorm) take a random walk that differs between ANY two runs (fp32
+    # atomics); what must agree is the update as a whole: direction of the total parameter change, and its size
+    start = {n: p.detach().float() for n, p in make()[0].named_parameters()}
+    de = torch.cat([(finals['eager'][n] - start[n]).flatten() for n in start]).double()
+    dg = torch.cat([(finals['graph'][n] - start[n]).flatten() for n in start]).double()
+    cos = torch.nn.functional.cosine_similarity(de, dg, dim=0).item()
+    ratio = (dg.norm() / de.norm()).item()
+    moved = de.abs().max().item()
+    print(f'\n[hipGraph step vs eager] losses {losses["eager"][-1]} / {losses["graph"][-1]}; update cosine {cos:.5f}, norm ratio {ratio:.4f}, largest move {moved:.2e}')
+    _log_parity('graphed_step_vs_eager', dict(update_cosine=cos, update_norm_ratio=ratio, last_loss_eager=losses['eager'][-1]['loss'], last_loss_graph=losses['graph'][-1]['loss']))
+    assert moved > 1e-4 and cos >= 0.97 and abs(ratio - 1) <= 0.02, (cos, ratio, moved)
+
+
+def test_dropout_counter_changes_the_mask_per_replay(dev):
+    """The dropout masks of the neck's glue kernels are a hash of (seed ARGUMENT, element): captured in a graph the argument is frozen.
+    With ge_rng_salt registered the device counter enters the hash at execution time: same seed, different counter -> different mask;
+    forward and backward of one step (same counter) agree; no counter -> the round-4 behaviour."""
+    from gedepth_amd import hip, kernels as K
+    tok = torch.randn(2, 64, 128, device=dev).bfloat16()
+    ident = torch.zeros_like(tok)
+    salt = torch.zeros(1, device=dev, dtype=torch.int64)
+    base = K.residual_dropout(ident, tok, 0.5, seed=77).float()
+    hip.check(hip.lib().ge_rng_salt(salt.data_ptr()), 'ge_rng_salt')
+    try:
+        outs = []
+        for v in (0, 1, 2, 1):
+            salt.fill_(v)
+            t = tok.clone().requires_grad_(True)
+            o = K.residual_dropout(ident, t, 0.5, seed=77)
+            o.float().sum().backward()
+            kept_f, kept_b = (o != 0), (t.grad != 0)
+            assert torch.equal(kept_f, kept_b), 'backward must regenerate the forward mask'
+            outs.append(o.float())
+    finally:
+        hip.lib().ge_rng_salt(None)
+    assert torch.equal(outs[0], base)                       # counter 0 = no counter
+    assert torch.equal(outs[1], outs[3]) and not torch.equal(outs[1], outs[2]) and not torch.equal(outs[0], outs[1])
+    keep = [(o != 0).float().mean().item() for o in outs]
+    assert all(abs(k - 0.5) < 0.03 for k in keep), keep
+    assert torch.equal(K.residual_dropout(ident, tok, 0.5, seed=77).float(), base)

@@ -14,7 +14,11 @@ import os.path as osp
 import sys
 import time
 
-import torch
+# ROCm 7.2: graph replays that run while another stream copies host -> device faulted ("illegal memory access") with the runtime's
+# AQL-packet capture of graph kernels on; without it the same runs are clean and as fast (gedepth_amd/mmrt/graph.py).  Read at HIP start-up.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')
+
+import torch  # noqa: E402
 
 sys.path.insert(0, osp.dirname(osp.dirname(osp.abspath(__file__))))
 
@@ -45,6 +49,8 @@ def parse_args():
                    help='KITTI: loader workers only decode files; ground depth from the calibration and every transform of the train '
                         'pipeline run on the GPU (gedepth_amd/depth/datasets/gpu_pipeline.py, SURVEY.md §8 f3)')
     p.add_argument('--pe-source', default='calib', choices=['calib', 'npy'], help='--gpu-pipeline: ground depth from the calibration files or from pe_165.npy')
+    p.add_argument('--hip-graph', action='store_true',
+                   help='capture the training step in a hipGraph after three eager iterations (gedepth_amd/mmrt/graph.py): one launch per iteration')
     p.add_argument('--layout', default='nhwc', choices=['nchw', 'nhwc'], help='nhwc: channels-last conv stack (depth/models/utils/layout.py)')
     p.add_argument('--gemm-tuning', default='load', choices=['off', 'load', 'tune'],
                    help='hipBLASLt/rocBLAS solution table for the Linear layers (gedepth_amd/mmrt/tuning.py)')
@@ -61,6 +67,8 @@ def main():
         cfg.load_from = args.load_from
     if args.resume_from:
         cfg.resume_from = args.resume_from
+    if args.hip_graph:
+        cfg.hip_graph = True
     if args.bf16:
         cfg.amp = 'bf16'
     if args.fp32:
