@@ -242,9 +242,8 @@ def test_full_size_forward_vs_oracle(dev):
     rel = ((out.cpu() - ref).abs() / ref.abs().clamp_min(1e-3))
     print(f'\n[full size 1x352x1120 Swin-T-V] eval depth rel err vs fp32 oracle: max {rel.max().item():.2e} mean {rel.mean().item():.2e}')
     _log_parity('full_size_T_V', dict(depth_max_rel=rel.max().item(), depth_mean_rel=rel.mean().item()))
-    # two fp32 evaluations (CPU oracle / HIP) of the same 12-block network: each is ~4e-5 from float64 at 64x96
-    # (test_e2e_vs_reference_fixture), so their mutual distance is bounded by 2e-4; the mean stays 20x below 1e-4
-    assert rel.max().item() <= 2e-4, rel.max().item()
+    # north_star: predicted depth within 1e-4 relative in fp32 (measured 2.5e-5 max, 1.0e-6 mean at this size)
+    assert rel.max().item() <= 1e-4, rel.max().item()
     assert rel.mean().item() <= 5e-6, rel.mean().item()
 
 
@@ -579,6 +578,32 @@ def test_config3_swinl_adaptive_full_shape_bf16_step_vs_fp32(dev):
     optimizer.step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in model.parameters())
+    # Second phase (round-4 review): the bound above on the cross-attention's offset projection asserts little because AT INITIALISATION
+    # that gradient is the residue of cancelling zero-mean terms.  After 20 optimizer steps the value maps carry structure and the
+    # same comparison is well-conditioned: bf16 step vs fp32 step at the trained state, the two tensors held to cosine >= 0.95.
+    for _ in range(19):
+        optimizer.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            o = model.train_step(batch, optimizer)
+        o['loss'].backward()
+        optimizer.step()
+    optimizer.zero_grad()
+    optimizer.arena.refresh_shadow(copy=True)
+    r2 = model.train_step(batch, None)                      # fp32 at the trained state
+    r2['loss'].backward()
+    optimizer.arena.collect()
+    t32 = {n: p.grad.detach().double().flatten().clone() for n, p in model.named_parameters() if n in msda_names}
+    optimizer.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        o2 = model.train_step(batch, optimizer)
+    o2['loss'].backward()
+    optimizer.arena.collect()
+    per2 = {n: torch.nn.functional.cosine_similarity(p.grad.detach().double().flatten(), t32[n], dim=0).item()
+            for n, p in model.named_parameters() if n in msda_names}
+    for n, c in per2.items():
+        print(f'   after 20 steps {n:48s} cosine {c:.5f}  |g32| {t32[n].norm().item():.3e}')
+    _log_parity('config3_bf16_vs_fp32_after_20_steps', dict(per_projection_cosine=per2, loss_fp32=dict(r2['log_vars']), loss_bf16=dict(o2['log_vars'])))
+    assert all(per2[n] >= 0.95 for n in cross_offsets), per2
 
 
 def test_config5_fp8_window_attention_workload(dev):
