@@ -39,7 +39,12 @@ def run(active):
         ddp.finish()
         if it == 0:
             torch.cuda.synchronize()
-            grad = optimizer.arena.flat_grad.detach().clone()        # after the (averaging) all-reduce of world size 1
+            # after the (averaging) all-reduce of world size 1; in REGISTRATION order: the active run has just permuted its arena into
+            # gradient-arrival order (FlatDDP._learn_arrival_order), the other keeps the registration layout
+            optimizer.arena.collect()
+            grad = torch.cat([p.grad.detach().reshape(-1) for p in model.parameters()]).clone()
+            if active:
+                assert ddp._order_learned and [id(p) for p in optimizer.arena.params] != [id(p) for p in model.parameters() if p.requires_grad]
         optimizer.step()
         losses.append(float(out['log_vars']['loss']))
     torch.cuda.synchronize()

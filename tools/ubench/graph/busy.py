@@ -23,3 +23,14 @@ print(f'last {N} steps: {(t1 - t0) / N / 1e6:.3f} ms/step wall, {busy / N / 1e6:
       f'{len(win) / N:.0f} launches/step, idle {(1 - union / (t1 - t0)) * 100:.1f} %')
 short = sum(1 for s, e, n in win if e - s < 10000)
 print(f'   kernels shorter than 10 us: {short / N:.0f} per step; mean gap between consecutive kernels {((t1 - t0) - union) / max(1, len(win)) / 1e3:.2f} us')
+
+import collections, re
+agg = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n_ in win:
+    key = re.sub(r'<.*', '', n_.replace('void ', ''))[:70]
+    agg[key][0] += e_ - s_; agg[key][1] += 1
+print('   top kernels (ms/step, launches/step):')
+for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 25]:
+    print(f'      {t / N / 1e6:7.3f} {c / N:7.1f}  {k}')
+tiny = sum(e_ - s_ for s_, e_, n_ in win if e_ - s_ < 10000)
+print(f'   time inside kernels shorter than 10 us: {tiny / N / 1e6:.3f} ms/step')
