@@ -32,8 +32,8 @@ MFMA_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak (same guide)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)          # 10 warm-up + 50 timed steps
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='depthformer_swint_v.py', help='file under configs/depthformer/')
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: data.samples_per_gpu)')
     ap.add_argument('--height', type=int, default=352)
@@ -378,6 +378,8 @@ def main():
                                'algorithmic_bytes_per_launch': int(dom['bytes_per_launch']),
                                'timed': f'HIP events on the launch stream, separate pass of {args.profile_steps} steps after the timed region'}
             res['roofline']['traffic'] = pmc_traffic(dom['name'].split('[')[0])
+            res['roofline']['traffic_source'] = ('profiles/pmc_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                                                 'of this workload (tools/profile_bench.sh), not counters of THIS run')
             step_ms = 1e3 * elapsed / args.steps
             def krow(r):
                 row = {'name': r['name'], 'launches': r['launches'], 'avg_us': round(r['avg_us'], 2),
