@@ -46,6 +46,15 @@ typedef short mm_s16x2 __attribute__((ext_vector_type(2)));
 #define MM_HALF (MM_CAP * 32 + 32)       // bf16 elements of one channel-half image of the stage: [rows][32 channels] + 64 B skew
 #define MM_STAGE (2 * MM_HALF)
 #define MM_IMG ((MM_CAP + 4) * 32)       // coefficient image, TRANSPOSED: [window row k][32 queries] bf16 (+ 4 dump rows), see the kernel
+#ifndef MF_CAP
+#define MF_CAP 96                        // the same for the FORWARD kernel.  With the model's reference points (un-normalised sine embedding: a 32-query
+                                         // tile spans ~4 x 3 level-0 cells) the two levels of a pass need ~80 rows: one chunk of 96 instead of two of 64:
+                                         // forward 2.27 -> 2.02 ms (80: 2.09, 128: 2.39); the d_raw kernel is fastest at 64 (2.36; 96: 2.69) — its fp32
+                                         // S^T image is twice the size per row (tools/ubench/msda_mm/dv_variants.sh, round 5)
+#endif
+#define MF_HALF (MF_CAP * 32 + 32)
+#define MF_STAGE (2 * MF_HALF)
+#define MF_IMG ((MF_CAP + 4) * 32)
 #ifndef MM_WAVES
 #define MM_WAVES 2                       // occupancy target per SIMD (registers); LDS allows 160 KB / (image + stage) per CU.  Measured with 3
                                          // (168 VGPRs: 28 / 56 spilled registers in forward / d_raw): forward 2.19 vs 2.20 ms, d_raw 3.29 vs 2.43 ms
@@ -181,6 +190,7 @@ struct MmWin {
 // registers; destination = wave-uniform base + lane * 16 bytes).  One instruction moves 16 rows x 64 bytes of ONE channel half: lane ->
 // (row = lane / 4, 16-byte piece = lane % 4), which is exactly a 1 KB run of the stage's [half][row][32 channels] image.  Rows past the
 // window read a row that exists (their coefficient columns are zero).
+template <int HALF>
 __device__ __forceinline__ void mm_stage_rows(const MmWin& w, int c0, int n16, int lane, int nh64, bf16_t* stage) {
   const int piece = (lane & 3) * 8;
   for (int j = 0; j < n16; ++j) {
@@ -194,7 +204,7 @@ __device__ __forceinline__ void mm_stage_rows(const MmWin& w, int c0, int n16, i
     const bf16_t* src = w.vb + (uint32_t)(mul24(pix, nh64) + piece);      // uniform base + 32-bit element offset (launcher: < 2^31)
     if (!(MM_DIAG & 1)) {
       __builtin_amdgcn_global_load_lds(src, MM_LDS_PTR(void, stage + j * 16 * 32), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(src + 32, MM_LDS_PTR(void, stage + MM_HALF + j * 16 * 32), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src + 32, MM_LDS_PTR(void, stage + HALF + j * 16 * 32), 16, 0, 0);
     }
   }
 }
@@ -205,8 +215,8 @@ __device__ __forceinline__ void mm_stage_rows(const MmWin& w, int c0, int n16, i
 // operand (8 consecutive k of one query per lane) comes back through the same transposing read as the B operand.
 template <bool LOC>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVES, MM_WAVES))) msda_mm_fwd_k(MmArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t cimg[MM_IMG];
-  __shared__ __attribute__((aligned(16))) bf16_t stage2[(1 + MM_DBUF) * MM_STAGE];   // MM_DBUF: the next chunk's LDS-DMA runs under this one's MFMAs
+  __shared__ __attribute__((aligned(16))) bf16_t cimg[MF_IMG];
+  __shared__ __attribute__((aligned(16))) bf16_t stage2[(1 + MM_DBUF) * MF_STAGE];   // MM_DBUF: the next chunk's LDS-DMA runs under this one's MFMAs
   const int nh64 = a.nH * 64;
   const long total = (long)a.B * a.nH * a.ntiles;
   // XCD x (= blockIdx % 8) walks the x-th contiguous eighth of the (image, head, tile) list: what it has in flight samples one
@@ -276,7 +286,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
       if (w.Ktot == 0) continue;                                          // nothing of this tile samples these levels (uniform)
       w.ibwA = 1.f / (float)max(w.bwA, 1); w.ibwB = 1.f / (float)max(w.bwB, 1);
       w.startA = a.lv.start[s]; w.startB = a.lv.start[s + 2]; w.vb = vb;
-      mm_stage_rows(w, 0, (min(MM_CAP, w.Ktot) + 15) >> 4, lane, nh64, stage2);      // first chunk in flight under the index arithmetic + scatter
+      mm_stage_rows<MF_HALF>(w, 0, (min(MF_CAP, w.Ktot) + 15) >> 4, lane, nh64, stage2);      // first chunk in flight under the index arithmetic + scatter
       const int bw_l = hv ? w.bwB : w.bwA;
       {   // window row of corner 00 in the concatenated K axis; points without a tap inside the map point at row 0 with zero weights
         const int xmin = hv ? w.xminB : w.xminA, ymin = hv ? w.yminB : w.yminA, kofs = hv ? w.KA : 0;
@@ -290,13 +300,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
       }
       bf16_t* crow = cimg + q;
 #pragma unroll 1
-      for (int c0 = 0, ci = 0; c0 < w.Ktot; c0 += MM_CAP, ci ^= 1) {
-        const int cols = min(MM_CAP, w.Ktot - c0);
+      for (int c0 = 0, ci = 0; c0 < w.Ktot; c0 += MF_CAP, ci ^= 1) {
+        const int cols = min(MF_CAP, w.Ktot - c0);
         const int n16 = (cols + 15) >> 4;
-        bf16_t* stage = stage2 + (MM_DBUF ? ci : 0) * MM_STAGE;
+        bf16_t* stage = stage2 + (MM_DBUF ? ci : 0) * MF_STAGE;
         if (!MM_DBUF && c0) {                                             // single buffer: this chunk's rows start now, under the scatter
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          mm_stage_rows(w, c0, n16, lane, nh64, stage);
+          mm_stage_rows<MF_HALF>(w, c0, n16, lane, nh64, stage);
         }
         __builtin_amdgcn_wave_barrier();
         {   // clear the n16 * 16 rows this chunk uses: 1 KB per step
@@ -319,18 +329,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
             const float w00 = (float)wt2[0], w01 = (float)wt2[1], w10 = (float)wb2[0], w11 = (float)wb2[1];
             // masked corners and corners of another chunk go to one of the four dump rows behind the image (a clamped corner may alias
             // its live neighbour: it must not be written)
-            const bool o00 = (unsigned)r00 < (unsigned)MM_CAP && w00 != 0.f, o01 = (unsigned)(r00 + dx) < (unsigned)MM_CAP && w01 != 0.f;
-            const bool o10 = (unsigned)r10 < (unsigned)MM_CAP && w10 != 0.f, o11 = (unsigned)(r10 + dx) < (unsigned)MM_CAP && w11 != 0.f;
+            const bool o00 = (unsigned)r00 < (unsigned)MF_CAP && w00 != 0.f, o01 = (unsigned)(r00 + dx) < (unsigned)MF_CAP && w01 != 0.f;
+            const bool o10 = (unsigned)r10 < (unsigned)MF_CAP && w10 != 0.f, o11 = (unsigned)(r10 + dx) < (unsigned)MF_CAP && w11 != 0.f;
             if (__builtin_amdgcn_ballot_w64(o00 || o01 || o10 || o11) == 0) continue;      // no lane's point p reaches this chunk (uniform)
-            const int i00 = (o00 ? r00 : MM_CAP) * 32, i01 = (o01 ? r00 + dx : MM_CAP + 1) * 32;
-            const int i10 = (o10 ? r10 : MM_CAP + 2) * 32, i11 = (o11 ? r10 + dx : MM_CAP + 3) * 32;
+            const int i00 = (o00 ? r00 : MF_CAP) * 32, i01 = (o01 ? r00 + dx : MF_CAP + 1) * 32;
+            const int i10 = (o10 ? r10 : MF_CAP + 2) * 32, i11 = (o11 ? r10 + dx : MF_CAP + 3) * 32;
             const float v00 = bf2f(crow[i00]) + w00, v01 = bf2f(crow[i01]) + w01, v10 = bf2f(crow[i10]) + w10, v11 = bf2f(crow[i11]) + w11;
             crow[i00] = mm_bf(v00); crow[i01] = mm_bf(v01); crow[i10] = mm_bf(v10); crow[i11] = mm_bf(v11);
           }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this chunk's LDS-DMA has landed; earlier operand reads are done
-        if (MM_DBUF && c0 + MM_CAP < w.Ktot)                              // next chunk -> the other buffer, under this chunk's MFMAs
-          mm_stage_rows(w, c0 + MM_CAP, (min(MM_CAP, w.Ktot - c0 - MM_CAP) + 15) >> 4, lane, nh64, stage2 + (ci ^ 1) * MM_STAGE);
+        if (MM_DBUF && c0 + MF_CAP < w.Ktot)                              // next chunk -> the other buffer, under this chunk's MFMAs
+          mm_stage_rows<MF_HALF>(w, c0 + MF_CAP, (min(MF_CAP, w.Ktot - c0 - MF_CAP) + 15) >> 4, lane, nh64, stage2 + (ci ^ 1) * MF_STAGE);
         __builtin_amdgcn_wave_barrier();
         if (!(MM_DIAG & 4)) {
 #pragma unroll 1
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
             const mm_bf16x8 A = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-              const bf16_t* p = stage + half * MM_HALF + (ks * 16 + tr_row) * 32 + tr_col;
+              const bf16_t* p = stage + half * MF_HALF + (ks * 16 + tr_row) * 32 + tr_col;
               const mm_bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, p));
               const mm_bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, p + 4 * 32));
               const mm_bf16x8 Bv = __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -499,7 +509,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
       if (w.Ktot > 0) {                                                   // uniform
         w.ibwA = 1.f / (float)max(w.bwA, 1); w.ibwB = 1.f / (float)max(w.bwB, 1);
         w.startA = a.lv.start[s]; w.startB = a.lv.start[s + 2]; w.vb = vb;
-        mm_stage_rows(w, 0, (min(MM_CAP, w.Ktot) + 15) >> 4, lane, nh64, stage2);
+        mm_stage_rows<MM_HALF>(w, 0, (min(MM_CAP, w.Ktot) + 15) >> 4, lane, nh64, stage2);
         const int bw_l = hv ? w.bwB : w.bwA;
         {
           const int xmin = hv ? w.xminB : w.xminA, ymin = hv ? w.yminB : w.yminA, kofs = hv ? w.KA : 0;
@@ -518,11 +528,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
           bf16_t* stage = stage2 + (MM_DBUF ? ci : 0) * MM_STAGE;
           if (!MM_DBUF && c0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mm_stage_rows(w, c0, n16, lane, nh64, stage);
+            mm_stage_rows<MM_HALF>(w, c0, n16, lane, nh64, stage);
           }
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this chunk has landed; the previous chunk's reads are done
           if (MM_DBUF && c0 + MM_CAP < w.Ktot)
-            mm_stage_rows(w, c0 + MM_CAP, (min(MM_CAP, w.Ktot - c0 - MM_CAP) + 15) >> 4, lane, nh64, stage2 + (ci ^ 1) * MM_STAGE);
+            mm_stage_rows<MM_HALF>(w, c0 + MM_CAP, (min(MM_CAP, w.Ktot - c0 - MM_CAP) + 15) >> 4, lane, nh64, stage2 + (ci ^ 1) * MM_STAGE);
           __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
           for (int mb = 0; mb < (n16 + 1) >> 1; ++mb) {

@@ -926,6 +926,7 @@ class _Conv3x3(torch.autograd.Function):
         y = _conv3x3_launch(x, w_ohwi, b32, act, slope)
         ctx.save_for_backward(x, wb, y if act else None)
         ctx.meta = (act, slope, bias is not None, weight.dtype, None if bias is None else bias.dtype)
+        ctx.weight_ref = weight if isinstance(weight, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -962,14 +963,19 @@ class _Conv3x3(torch.autograd.Function):
                 px, gflop = N * H * W, 18e-9 * N * H * W * Ci * Co
                 if 'conv3x3_wgrad' not in DISABLED and w_dtype == _f32 and (px >= 10000 or (N <= 4 and px >= 2000 and gflop >= 25.0)):
                     # MFMA weight gradient, fp32 accumulation straight into an (O, H, W, I) tensor = a channels-last (O, I, 3, 3) gradient
-                    dw_ohwi = torch.zeros(Co, 3, 3, Ci, device=dy.device, dtype=_f32)
+                    from .mmrt.optim import grad_target_ohwi
+                    dw_ohwi = grad_target_ohwi(ctx.weight_ref) if ctx.weight_ref is not None else None      # the arena slice itself: no copy later
+                    if dw_ohwi is None or tuple(dw_ohwi.shape) != (Co, 3, 3, Ci):
+                        dw_ohwi = torch.empty(Co, 3, 3, Ci, device=dy.device, dtype=_f32)
+                    dw_ohwi.zero_()
                     PROFILER.run(f'conv3x3_wgrad[{N}x{Ci}->{Co} {H}x{W}]', (x.numel() + dy.numel()) * 2 + dw_ohwi.numel() * 4, lambda: hip.check(
                         hip.lib().ge_conv3x3_nhwc_wgrad(_raw_ptr(x, 'x'), _raw_ptr(dy, 'dy'), hip.ptr(dw_ohwi), N, H, W, Ci, Co, hip.GE_BF16, hip.stream()),
                         'ge_conv3x3_nhwc_wgrad'), flops=2 * N * H * W * Ci * Co * 9)
                     dw = dw_ohwi.permute(0, 3, 1, 2)
                 else:
                     dw = torch.ops.aten.convolution_backward(dy, x, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-                    dw = dw.to(w_dtype)
+                    from .mmrt.optim import grad_into_arena
+                    dw = grad_into_arena(ctx.weight_ref, dw, w_dtype)
         return dx, dw, (None if db is None else db.to(b_dtype)), None, None
 
 
@@ -1008,6 +1014,7 @@ class _ConvLib(torch.autograd.Function):
             y = torch.nn.functional.conv2d(xc, wc, None, stride, padding, dilation, groups)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (stride, padding, dilation, groups, x.dtype, weight.dtype)
+        ctx.weight_ref = weight if isinstance(weight, torch.nn.Parameter) else None
         return y
 
     @staticmethod
@@ -1021,7 +1028,10 @@ class _ConvLib(torch.autograd.Function):
                                                             (ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_dw, False))
         if own_dw:
             dw = conv1x1_wgrad(xc, dy).view(wc.shape)
-        return (None if dx is None else dx.to(x_dtype)), (None if dw is None else dw.to(w_dtype)), None, None, None, None
+        if dw is not None:
+            from .mmrt.optim import grad_into_arena
+            dw = grad_into_arena(ctx.weight_ref, dw, w_dtype)
+        return (None if dx is None else dx.to(x_dtype)), dw, None, None, None, None
 
 
 def conv1x1_wgrad_ok(x, dy, w, stride, padding, dilation, groups):

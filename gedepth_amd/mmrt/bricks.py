@@ -139,6 +139,22 @@ def _linear_dx(dy2, wc):
     return dy2 @ wc
 
 
+def _sum_partials(part, weight, w_dtype):
+    """fp32 sum of the split-K partial products — written straight into the parameter's slice of the gradient arena when this is the
+    parameter's first gradient of the step (optim.grad_target), else into a new tensor."""
+    if weight is not None and w_dtype == torch.float32:
+        from .optim import grad_target
+        out = grad_target(weight)
+        if out is not None and out.shape == part.shape[1:]:
+            return torch.sum(part, 0, dtype=torch.float32, out=out)
+    return part.sum(0, dtype=torch.float32).to(w_dtype)
+
+
+def _finished_grad(dw, weight, w_dtype):
+    from .optim import grad_into_arena
+    return grad_into_arena(weight, dw, w_dtype) if weight is not None else dw.to(w_dtype)
+
+
 class _LinearTokens(torch.autograd.Function):
     """``F.linear`` whose weight gradient is computed split-K.  dW = dY^T X has an output of at most 768 x 768 and a
     reduction over 5e4 - 8e5 tokens: the libraries run it as one GEMM on a handful of output tiles (hipBLASLt / rocBLAS,
@@ -155,6 +171,7 @@ class _LinearTokens(torch.autograd.Function):
             y = _linear_fwd(xc, wc, weight, bias, dt)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (splits, x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.weight_ref = weight if isinstance(weight, nn.Parameter) else None
         return y
 
     @staticmethod
@@ -174,9 +191,9 @@ class _LinearTokens(torch.autograd.Function):
                 if splits:
                     M, N = dy2.shape[1], x2.shape[1]
                     part = torch.bmm(dy2.view(splits, K // splits, M).transpose(1, 2), x2.view(splits, K // splits, N))
-                    dw = part.sum(0, dtype=torch.float32).to(w_dtype)
+                    dw = _sum_partials(part, ctx.weight_ref, w_dtype)
                 else:
-                    dw = (dy2.t() @ x2).to(w_dtype)
+                    dw = _finished_grad(dy2.t() @ x2, ctx.weight_ref, w_dtype)
             if b_dtype is not None and ctx.needs_input_grad[2]:
                 if dy2.shape[1] % (4 if dy2.dtype == torch.float32 else 8) == 0:      # 16-byte channel vectors: one streaming pass
                     from .. import kernels
@@ -206,6 +223,7 @@ class _LinearBiasGelu(torch.autograd.Function):
             g = kernels.bias_gelu_fwd(y0, None)
         ctx.save_for_backward(xc, wc, y0)
         ctx.meta = (splits, x.dtype, weight.dtype, bias.dtype)
+        ctx.weight_ref = weight if isinstance(weight, nn.Parameter) else None
         return g
 
     @staticmethod
@@ -227,9 +245,9 @@ class _LinearBiasGelu(torch.autograd.Function):
                 if splits:
                     M, N = dy2.shape[1], x2.shape[1]
                     part = torch.bmm(dy2.view(splits, K // splits, M).transpose(1, 2), x2.view(splits, K // splits, N))
-                    dw = part.sum(0, dtype=torch.float32).to(w_dtype)
+                    dw = _sum_partials(part, ctx.weight_ref, w_dtype)
                 else:
-                    dw = (dy2.t() @ x2).to(w_dtype)
+                    dw = _finished_grad(dy2.t() @ x2, ctx.weight_ref, w_dtype)
         return dx, dw, (db.to(b_dtype) if ctx.needs_input_grad[2] else None), None
 
 

@@ -836,3 +836,49 @@ def test_dropout_counter_changes_the_mask_per_replay(dev):
     keep = [(o != 0).float().mean().item() for o in outs]
     assert all(abs(k - 0.5) < 0.03 for k in keep), keep
     assert torch.equal(K.residual_dropout(ident, tok, 0.5, seed=77).float(), base)
+
+
+def test_linear_weight_gradients_are_written_into_the_arena(dev):
+    """optim.grad_target: the split-K weight gradient of a token Linear is summed straight into the parameter's slice of the gradient arena
+    (autograd adopts the alias, GradArena.collect has nothing to copy).  Checked on the Swin-T model: after backward, before collect, the
+    large Linear weights' ``.grad`` IS arena memory; the gradients equal those of the copying path (slices hidden from the producers)."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    torch.manual_seed(0)
+    model = build('depthformer_swint_v.py')
+    load_filled(model, 'arena_grads')
+    model = model.to(dev).train()
+    opt = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+    batch = synthetic_batch(2, 352, 704, seed=3, device=dev, valid_fraction=0.3)
+    names = {id(p): n for n, p in model.named_parameters()}
+
+    def run():
+        opt.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = model.train_step(batch, opt)
+        out['loss'].backward()
+        direct = [names[id(p)] for p, v in zip(opt.arena.params, opt.arena.views) if p.grad is not None and p.grad.data_ptr() == v.data_ptr()]
+        opt.arena.collect()
+        return direct, {names[id(p)]: v.detach().clone() for p, v in zip(opt.arena.params, opt.arena.views)}
+    direct, g_new = run()
+    saved = [p._ge_grad_view for p in opt.arena.params]
+    for p in opt.arena.params:
+        p._ge_grad_view = None
+    direct_off, g_old = run()
+    for p, v in zip(opt.arena.params, saved):
+        p._ge_grad_view = v
+    assert not direct_off
+    big = [n for n in direct if n.endswith('.weight')]
+    elems = sum(g_new[n].numel() for n in direct)
+    print(f'\n[arena-direct gradients] {len(direct)} tensors, {elems / 1e6:.1f} M of {opt.arena.numel / 1e6:.1f} M elements: e.g. {big[:3]}')
+    assert any('attn.w_msa.qkv.weight' in n for n in direct) and any('ffn.layers.1.weight' in n for n in direct) and any('decode_head.conv_list' in n for n in direct), direct[:10]
+    assert elems >= 0.9 * opt.arena.numel, (elems, opt.arena.numel)        # Linear (split-K and plain) and convolution weights; what is left are biases / norms
+    # two runs of one step differ by the order of the fp32 atomics upstream (the earliest backbone layers, sums of cancelling terms, by up to
+    # ~2 %): per tensor 5 %, all of them together 1 %
+    for n in direct:
+        a, b = g_new[n].double(), g_old[n].double()
+        assert (a - b).norm() <= 5e-2 * b.norm() + 1e-12, (n, ((a - b).norm() / b.norm()).item())
+    A, B = torch.cat([g_new[n].double().flatten() for n in direct]), torch.cat([g_old[n].double().flatten() for n in direct])
+    assert ((A - B).norm() / B.norm()).item() <= 1e-2
