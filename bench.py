@@ -362,7 +362,8 @@ def main():
                                'note': 'same steps, batch copied from pinned host memory every step (non-blocking, side stream, double-buffered: '
                                        'overlaps the previous step); `value` above is with resident inputs, as the bench contract defines it'}
         res['ddp'] = ddp_info                                 # rank count as RCCL reports it, bucket layout, per-bucket overlap trace (N > 1)
-        res['msda_value_choice'] = [dict(shape=list(k[:4]), kernel='mfma transposed contraction' if c.use_mm else 'record pipeline', statistics=c.last)
+        res['msda_value_choice'] = [dict(shape=list(k[:4]), mfma_kernel_levels=[l for l in range(4) if (c.mm_mask >> l) & 1],
+                                         record_pipeline_levels=[l for l in range(4) if not (c.mm_mask >> l) & 1], statistics=c.last)
                                     for k, c in kernels._MM_VALUE_CHOICE.items()]      # cross-attention d_value: which kernel the run statistics chose
         res['eager_fallbacks'] = dict(kernels.FALLBACKS)      # modules that took ATen where a HIP kernel exists: must be empty
         assert not kernels.FALLBACKS, f'eager fall-backs inside the measured step: {kernels.FALLBACKS}'

@@ -580,7 +580,8 @@ __device__ __forceinline__ float msda_half_sum(float v) {
   return (threadIdx.x & 32) ? b : a;
 }
 template <bool FILL>
-__global__ void __launch_bounds__(1024) msda_hist_raw_k(MsdaLevels lv, MsdaBins bins, MsdaRawIn in, MsdaWs ws, int Nq, int nH, int R, int B) {
+__global__ void __launch_bounds__(1024) msda_hist_raw_k(MsdaLevels lv, MsdaBins bins, MsdaRawIn in, MsdaWs ws, int Nq, int nH, int R, int B,
+                                                        int level_mask) {
   extern __shared__ int hist[];
   const int ntiles = bins.first_tile[4];
   const int nunits = B * nH * R;
@@ -610,7 +611,8 @@ __global__ void __launch_bounds__(1024) msda_hist_raw_k(MsdaLevels lv, MsdaBins 
         const float e = __expf(lg - msda_half_max(lg));
         wgt = e * (1.f / msda_half_sum(e));
       }
-      if (!(live && y > -1.f && x > -1.f && y < fH && x < fW)) continue;
+      // level_mask: levels whose d_value another kernel produces (ge_msda_bwd_value_mm) leave no records here
+      if (!(live && ((level_mask >> l) & 1) && y > -1.f && x > -1.f && y < fH && x < fW)) continue;
       const int Hl = lv.H[l], Wl = lv.W[l];
       const float xf = floorf(x), yf = floorf(y);
       const int x0 = (int)xf, y0 = (int)yf;
@@ -1268,6 +1270,16 @@ extern "C" int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw,
                                      const float* ref, long ref_sb, long ref_sq, long ref_sl, const void* d_out, float* d_value,
                                      void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype,
                                      void* stream) {
+  return ge_msda_bwd_value_raw_levels(spatial_hw, off_raw, off_ld, logit_raw, logit_ld, ref, ref_sb, ref_sq, ref_sl, d_out, d_value, workspace,
+                                      workspace_bytes, 15, B, Nv, Nq, nH, L, P, dtype, stream);
+}
+
+// The same restricted to the levels of `level_mask` (bit l): the other levels' rows of d_value are left untouched — they come from
+// ge_msda_bwd_value_mm, whose cost depends on the level (coarse levels: long runs of query tiles share a window).
+extern "C" int ge_msda_bwd_value_raw_levels(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                                            const float* ref, long ref_sb, long ref_sq, long ref_sl, const void* d_out, float* d_value,
+                                            void* workspace, size_t workspace_bytes, int level_mask, int B, int Nv, int Nq, int nH, int L,
+                                            int P, int dtype, void* stream) {
   if (!spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_value || !workspace || B < 0 || Nq < 0 || nH <= 0) return GE_ERR_BAD_ARG;
   if (dtype != GE_BF16 || L != 4 || P != 8) return GE_ERR_UNSUPPORTED;
   MsdaLevels lv;
@@ -1297,7 +1309,7 @@ extern "C" int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw,
   if (he != hipSuccess) return (int)he;
   const unsigned hgrid = (unsigned)std::min((long)MSDA_HIST_WGS, (long)B * nH * pl.R);
   const size_t hsmem = (size_t)pl.ntiles * 4;
-  msda_hist_raw_k<false><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B);
+  msda_hist_raw_k<false><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B, level_mask);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 2, s);
   msda_scan_k<<<1, 1024, 0, s>>>(ws, nbins);
@@ -1309,7 +1321,7 @@ extern "C" int ge_msda_bwd_value_raw(const int* spatial_hw, const void* off_raw,
     GE_LAUNCH_CHECK();
   } else ws.order = nullptr;                               // bin order
   msda_mark(ev, 3, s);
-  msda_hist_raw_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B);
+  msda_hist_raw_k<true><<<hgrid, 1024, hsmem, s>>>(lv, bins, in, ws, Nq, nH, pl.R, B, level_mask);
   GE_LAUNCH_CHECK();
   msda_mark(ev, 4, s);
   g_msda_drain_mfma_used = true;

@@ -742,7 +742,7 @@ extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const
 #endif
 
 struct MvWs { int4* bbox; int4* runs; int* ctrl; long runs_cap; };      // ctrl[x] = runs of XCD x, ctrl[8 + x] = its work cursor,
-                                                                         // ctrl[16] = window rows flushed, ctrl[17] = tile passes (statistics)
+                                                                         // ctrl[16] = window rows flushed, ctrl[17] = tile passes (statistics), ctrl[18 + 2 l], ctrl[19 + 2 l] = the same of level l
 static size_t mv_ws_layout(int B, int Nq, int nH, char* base, MvWs* ws, size_t* ctrl_off = nullptr) {
   const long ntiles = (Nq + 31) / 32, segs = (long)B * nH * 4;
   const long cap = (segs + MSDA_XCDS - 1) / MSDA_XCDS * ntiles;           // runs of one XCD's segments at most
@@ -770,7 +770,7 @@ __device__ __forceinline__ MvBox mv_join(const MvBox& a, const MvBox& b) {
 // together (a tile that alone exceeds it: a run of its own, chunked by the consumer).  Runs without any tap inside the map are dropped.
 // Record (2 x int4): {segment = (image * nH + head) * 4 + level, first tile | tiles << 24, box 0: min y << 16 | min x, height << 16 | width},
 //                    {box 1: min y << 16 | min x, height << 16 | width, -, -}; an empty box has width = height = 0.
-__global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int nsegs) {
+__global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int nsegs, int level_mask) {
   const int seg = blockIdx.x, lane = threadIdx.x;
   const int xcd = (int)(((long)(seg >> 2) * MSDA_XCDS) / (nsegs >> 2));     // image-major: the mapping of the sampling kernels
   const int4* bb = ws.bbox + (long)seg * ntiles;
@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int ns
     if (k0 + k1 > 0 && t1 > t0) {
       nrows += k0 + k1;
       npass += (t1 - t0) * ((k0 + k1 + MV_CAP - 1) / MV_CAP);
-      if (lane == 0) {
+      if (lane == 0 && ((level_mask >> (seg & 3)) & 1)) {         // statistics for every level, work only for the requested ones
         const int slot = atomicAdd(ws.ctrl + xcd, 1);
         const bool s0 = k0 > 0, s1 = k1 > 0;
         list[2 * slot] = make_int4(seg, t0 | ((t1 - t0) << 24), s0 ? (c0.y0 << 16) | (c0.x0 & 0xffff) : 0,
@@ -807,7 +807,10 @@ __global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int ns
     }
   }
   emit(ntiles);
-  if (lane == 0 && nrows) { atomicAdd(ws.ctrl + 16, nrows); atomicAdd(ws.ctrl + 17, npass); }
+  if (lane == 0 && nrows) {
+    atomicAdd(ws.ctrl + 16, nrows); atomicAdd(ws.ctrl + 17, npass);
+    atomicAdd(ws.ctrl + 18 + 2 * (seg & 3), nrows); atomicAdd(ws.ctrl + 19 + 2 * (seg & 3), npass);      // the same per level
+  }
 }
 
 struct MvArgs {
@@ -1044,8 +1047,8 @@ extern "C" size_t ge_msda_bwd_mm_stats_offset(int B, int Nq, int nH, int L) {
 // ge_msda_bwd_lw_mm was given for the same inputs: its head holds the per-tile tap boxes that kernel leaves behind.
 extern "C" int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
                                     const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out,
-                                    float* d_value, void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P,
-                                    int dtype, void* stream) {
+                                    float* d_value, void* workspace, size_t workspace_bytes, int level_mask, int B, int Nv, int Nq, int nH,
+                                    int L, int P, int dtype, void* stream) {
   if (!spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !workspace || B < 0 || Nq < 0) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
@@ -1066,9 +1069,9 @@ extern "C" int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, 
   hipError_t he = hipMemsetAsync(va.ws.ctrl, 0, 32 * sizeof(int), s);
   if (he != hipSuccess) return (int)he;
   const int nsegs = B * nH * 4;
-  msda_mm_runs_k<<<(unsigned)nsegs, 64, 0, s>>>(va.ws, a.ntiles, nsegs);
+  msda_mm_runs_k<<<(unsigned)nsegs, 64, 0, s>>>(va.ws, a.ntiles, nsegs, d_value ? level_mask : 0);
   GE_LAUNCH_CHECK();
-  if (!d_value) return GE_OK;                   // statistics only (ge_msda_bwd_mm_stats_offset)
+  if (!d_value || !(level_mask & 15)) return GE_OK;     // statistics only (ge_msda_bwd_mm_stats_offset)
   static int per_cu = 0, n_cu = 0;
   if (!per_cu) {
     int dev = 0, v = 0;

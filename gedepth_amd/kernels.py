@@ -452,18 +452,24 @@ def msda_fwd_mm(value, raw, ref, spatial_shapes, order=None, want_loc=False, nH=
 
 
 class _MMValueChoice:
-    """Which d_value kernel the MFMA deformable attention uses for one problem shape.  The transposed-contraction kernel
-    (ge_msda_bwd_value_mm) costs ~2.1 ns per tile pass + ~0.28 ns per flushed window row (MI355X, tools/ubench/msda_mm/dv_time.py): 2.7 ms
-    at the KITTI shape with the reference points of an initialised model (runs of ~17 tiles share a window), 10 ms when every 32-query
-    tile has a window of its own; the record pipeline (ge_msda_bwd_value_raw) costs ~0.70 ns per (query, head) whatever the geometry
-    (4.4 ms).  The run cutter leaves {rows, passes} in the workspace; they are copied to pinned host memory asynchronously and read by a
-    LATER call (never a synchronisation), so the choice follows the geometry with a lag of a step.  GE_MSDA_VALUE=mm|records pins it."""
+    """Which d_value kernel the MFMA deformable attention uses for one problem shape (as a level mask: all levels or none by default).  The transposed-contraction kernel
+    (ge_msda_bwd_value_mm) costs ~2.1 ns per tile pass + ~0.28 ns per flushed window row (MI355X, tools/ubench/msda_mm/dv_time.py), i.e. it
+    depends on how many consecutive query tiles share a window: at the KITTI shape with the model's reference points (8 queries per level-0
+    cell) level 0 would take 5.3 ms, level 1 1.7, level 2 0.74, level 3 0.50; the record pipeline (ge_msda_bwd_value_raw_levels) costs
+    ~0.70 ns per (query, head) over the four levels whatever the geometry (1.1 ms per level).  The run cutter leaves {rows, passes} per level
+    in the workspace; they are copied to pinned host memory asynchronously and read by a LATER call (never a synchronisation), so the choice
+    follows the geometry with a lag of a step.  GE_MSDA_VALUE = mm | records | <level bit mask of the MFMA kernel> pins it."""
     NS_PASS, NS_ROW, NS_QH = 2.1, 0.28, 0.70
     EVERY = 16                                        # steady state: look at the statistics every 16th call
 
     def __init__(self):
-        self.use_mm, self.calls, self.pending, self.last = True, 0, None, None
-        self.forced = {'mm': True, 'records': False}.get(os.environ.get('GE_MSDA_VALUE', ''))
+        self.mm_mask, self.calls, self.pending, self.last = 15, 0, None, None
+        env = os.environ.get('GE_MSDA_VALUE', '')
+        self.forced = {'mm': 15, 'records': 0}.get(env, int(env) if env.isdigit() else None)
+
+    @property
+    def use_mm(self):
+        return self.mm_mask != 0
 
     def wants_stats(self):
         return self.forced is None and (self.calls <= 4 or self.calls % self.EVERY == 0) and not torch.cuda.is_current_stream_capturing()
@@ -471,8 +477,8 @@ class _MMValueChoice:
     def observe(self, ws, offset, n_qh):
         if self.forced is not None or torch.cuda.is_current_stream_capturing() or not self.wants_stats() or self.pending is not None:
             return
-        host = torch.empty(2, dtype=torch.int32).pin_memory()
-        host.copy_(ws[offset:offset + 8].view(torch.int32), non_blocking=True)
+        host = torch.empty(10, dtype=torch.int32).pin_memory()
+        host.copy_(ws[offset:offset + 40].view(torch.int32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending = (host, ev, n_qh)
@@ -483,26 +489,33 @@ class _MMValueChoice:
             return
         if self.pending is not None and self.pending[1].query():
             host, _, n_qh = self.pending
-            rows, passes = int(host[0]), int(host[1])
             self.pending = None
-            if passes > 0:
+            if int(host[1]) > 0:
+                rows, passes = int(host[0]), int(host[1])
                 t_mm, t_rec = self.NS_PASS * passes + self.NS_ROW * rows, self.NS_QH * n_qh
-                self.last = dict(rows=rows, passes=passes, mm_ms=t_mm * 1e-6, records_ms=t_rec * 1e-6)
-                # hysteresis: change only for a 10 % predicted gain
-                self.use_mm = t_mm < 0.9 * t_rec if not self.use_mm else t_mm < 1.1 * t_rec
+                # all levels on one kernel or the other.  A per-level split (coarse levels on the MFMA kernel, fine ones through the
+                # records: GE_MSDA_VALUE=12) is supported and tested but measured SLOWER at the KITTI shape: the record pipeline restricted
+                # to levels 0-1 still costs 3.3 of its 4.7 ms (its count / fill passes are bound by the per-point loads and tap arithmetic,
+                # not by the records they emit) and the MFMA kernel on levels 2-3 alone 2.0 ms (latency of a run's serial tile passes with half
+                # the runs to overlap): 5.4 vs 4.7 ms (tools/ubench/msda_mm/dv_time.py, round 5)
+                on = self.mm_mask == 15
+                self.mm_mask = 15 if t_mm < (1.1 if on else 0.9) * t_rec else 0          # hysteresis: change only for a 10 % predicted gain
+                self.last = dict(rows=rows, passes=passes, mm_ms=round(t_mm * 1e-6, 3), records_ms=round(t_rec * 1e-6, 3),
+                                 per_level=[dict(rows=int(host[2 + 2 * l]), passes=int(host[3 + 2 * l])) for l in range(4)])
 
 
 _MM_VALUE_CHOICE = {}
 
 
 def _mm_value_choice(key, mm_ok, rec_ok):
+    """-> (choice object, level mask of the MFMA kernel for this call)."""
     c = _MM_VALUE_CHOICE.get(key)
     if c is None:
         c = _MM_VALUE_CHOICE[key] = _MMValueChoice()
     c.update()
-    use = c.use_mm if c.forced is None else c.forced
-    use = False if not mm_ok else True if not rec_ok else use          # only one of the two covers this call: no choice to make
-    return c, use
+    mask = c.mm_mask if c.forced is None else c.forced
+    mask = 0 if not mm_ok else 15 if not rec_ok else mask            # only one of the two covers this call: no choice to make
+    return c, mask
 
 
 class _MSDeformAttnMM(torch.autograd.Function):
@@ -552,29 +565,34 @@ class _MSDeformAttnMM(torch.autograd.Function):
         if want_dv:
             d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
             rec_ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
-            choice, use_mm = _mm_value_choice((B, Nq, Nv, nH, shapes, str(value.device)), mm_ws is not None, rec_ws_bytes > 0)
+            choice, mm_mask = _mm_value_choice((B, Nq, Nv, nH, shapes, str(value.device)), mm_ws is not None, rec_ws_bytes > 0)
+            rec_mask = 15 & ~mm_mask
 
-            def value_mm(dv):
+            def value_mm(dv, mask):
                 return hip.check(lib.ge_msda_bwd_value_mm(
                     shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(order),
-                    hip.ptr(d_out), hip.ptr(dv), hip.ptr(mm_ws), mm_ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
+                    hip.ptr(d_out), hip.ptr(dv), hip.ptr(mm_ws), mm_ws_bytes, mask, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
                     'ge_msda_bwd_value_mm')
-            if use_mm:
-                # algorithmic bytes: the raw projections + d_out read once, d_value written once
-                PROFILER.run(f'msda_mm_bwd_v_k[B{B} Nq{Nq} Nv{Nv}]', raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4, lambda: value_mm(d_value))
-            else:
+            if mm_mask:
+                # algorithmic bytes: the raw projections + d_out read once per level, those levels' d_value rows written once
+                lv_rows = sum(h * w for l, (h, w) in enumerate(shapes) if (mm_mask >> l) & 1)
+                PROFILER.run(f'msda_mm_bwd_v_k[B{B} Nq{Nq} Nv{Nv} levels {mm_mask:04b}]',
+                             bin(mm_mask).count('1') * (raw.numel() // 2 + d_out.numel() * 2 // 4) + B * lv_rows * nH * D * 4, lambda: value_mm(d_value, mm_mask))
+            elif mm_ws is not None and choice.wants_stats():
+                value_mm(None, 0)                   # run statistics only (~50 us): keeps the choice informed while the record path runs
+            if rec_mask:
                 if rec_ws_bytes <= 0:
                     raise RuntimeError('ms_deform_attn_mm backward: neither the MFMA d_value kernel nor the binned path covers this geometry')
-                if mm_ws is not None and choice.wants_stats():
-                    value_mm(None)                  # run statistics only (~50 us): keeps the choice informed while the record path runs
                 ws = torch.empty(rec_ws_bytes, device=value.device, dtype=torch.uint8)
+                frac = bin(rec_mask).count('1') / 4
                 if PROFILER.on:       # algorithmic bytes per stage: count reads the offsets, fill offsets + logits, drain d_out + d_value
-                    PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, d_out.numel() * 2 + d_value.numel() * 4))
-                PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}]', B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
-                             lambda: hip.check(lib.ge_msda_bwd_value_raw(
+                    PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, int(frac * d_out.numel() * 2) + d_value.numel() * 4))
+                PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}{"" if rec_mask == 15 else f" levels {rec_mask:04b}"}]',
+                             B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
+                             lambda: hip.check(lib.ge_msda_bwd_value_raw_levels(
                                  shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
-                                 hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), rec_ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value),
-                                 hip.stream()), 'ge_msda_bwd_value_raw'))
+                                 hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), rec_ws_bytes, rec_mask, B, Nv, Nq, nH, L, P, hip.dtype_code(value),
+                                 hip.stream()), 'ge_msda_bwd_value_raw_levels'))
             if mm_ws is not None:
                 choice.observe(mm_ws, int(lib.ge_msda_bwd_mm_stats_offset(B, Nq, nH, L)), B * Nq * nH)
             d_value = d_value.to(value.dtype)

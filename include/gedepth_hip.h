@@ -204,9 +204,16 @@ int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_
  * entry point and ge_msda_bwd_value_raw, whose cost is independent of the geometry. */
 size_t ge_msda_bwd_mm_workspace(int B, int Nq, int nH, int L);
 size_t ge_msda_bwd_mm_stats_offset(int B, int Nq, int nH, int L);
+/* `level_mask` (bit l = value level l): ge_msda_bwd_value_mm adds the d_value rows of those levels only, and
+ * ge_msda_bwd_value_raw_levels (the record pipeline restricted the same way) takes the complement — the statistics are per level too
+ * (ints 2 + 2 l, 3 + 2 l behind the two totals): coarse levels, where consecutive query tiles share their window, go to the MFMA kernel,
+ * fine levels to the records. */
 int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
                          long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, float* d_value, void* workspace,
-                         size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+                         size_t workspace_bytes, int level_mask, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+int ge_msda_bwd_value_raw_levels(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                                 const float* ref, long ref_sb, long ref_sq, long ref_sl, const void* d_out, float* d_value, void* workspace,
+                                 size_t workspace_bytes, int level_mask, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 int ge_msda_bwd_value(const void* value, const int* spatial_hw, const float* loc, const float* attw, const void* d_out, float* d_value,
                       void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 /* ge_msda_bwd_value fed from the raw projections instead of loc / attw (bf16, L == 4, P == 8; 8-byte records): with it the forward

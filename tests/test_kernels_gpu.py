@@ -593,15 +593,20 @@ def test_msda_mm_fwd_bwd_vs_oracle(dev, case):
               d_logits=l2rel(r.grad[..., n_off:].float(), rc.grad[..., n_off:]))
     print(f'\n[msda mm {case}] l2-relative errors vs the fp32 oracle on bf16-rounded inputs: ' + ', '.join(f'{k} {e:.2e}' for k, e in l2.items()))
     assert all(e <= 5e-3 for e in l2.values()), l2
-    # d_value through the record pipeline (GE_DISABLE=msda_value_mm: ge_msda_bwd_value_raw) stays covered and agrees
-    K.DISABLED.add('msda_value_mm')
-    try:
-        v2, r2 = value.to(dev).requires_grad_(True), raw.to(dev).requires_grad_(True)
-        K.ms_deform_attn_mm(v2, r2, ref.to(dev), shapes, order, nH, L, P).backward(go.to(dev))
-    finally:
-        K.DISABLED.discard('msda_value_mm')
-    close_scaled(v2.grad.float(), vc.grad, rel=1e-2, what='d value (record pipeline)')
-    assert torch.equal(r2.grad, r.grad)
+    # d_value comes from two kernels selected by a LEVEL MASK (kernels._MMValueChoice; the call above ran all levels on the MFMA kernel):
+    # every split must give the same tensor — all levels through the record pipeline, coarse / fine and odd / even splits
+    for mode in ('records', '12', '5', '10'):
+        K._MM_VALUE_CHOICE.clear()
+        os.environ['GE_MSDA_VALUE'] = mode
+        try:
+            v2, r2 = value.to(dev).requires_grad_(True), raw.to(dev).requires_grad_(True)
+            K.ms_deform_attn_mm(v2, r2, ref.to(dev), shapes, order, nH, L, P).backward(go.to(dev))
+        finally:
+            os.environ.pop('GE_MSDA_VALUE', None)
+            K._MM_VALUE_CHOICE.clear()
+        close_scaled(v2.grad.float(), vc.grad, rel=1e-2, what=f'd value (GE_MSDA_VALUE={mode})')
+        assert l2rel(v2.grad.float(), vc.grad) <= 5e-3, (mode, l2rel(v2.grad.float(), vc.grad))
+        assert torch.equal(r2.grad, r.grad)
     # the same call in another order: identical up to the bf16 rounding of the coefficient sums (different tiles, different chunking)
     other = torch.arange(nq - 1, -1, -1, dtype=torch.int32, device=dev)
     out2 = K.ms_deform_attn_mm(v.detach(), r.detach(), f.detach(), shapes, other, nH, L, P)

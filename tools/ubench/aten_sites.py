@@ -11,7 +11,7 @@ import bench  # noqa: E402
 
 
 def main():
-    sys.argv = ['bench.py', '--no-cpu-baseline', '--no-fp32', '--no-kernel-timing']
+    sys.argv = ['bench.py', '--no-cpu-baseline', '--no-fp32', '--no-kernel-timing', '--graph', 'off'] + (['--config', os.environ['CFG']] if os.environ.get('CFG') else [])
     args = bench.parse()
     from gedepth_amd.mmrt.config import Config
     from gedepth_amd.mmrt.tuning import use_miopen_find_db, use_tuned_gemms
@@ -19,6 +19,7 @@ def main():
     use_tuned_gemms('load')
     torch.backends.cudnn.benchmark = True
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', args.config))
+    cfg.model.pretrained = None
     dev = torch.device('cuda', 0)
     step, per_gpu, opt = bench.build_job(args, cfg, dev, 0, 'bf16')
     for _ in range(4):

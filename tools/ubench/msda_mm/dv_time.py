@@ -36,8 +36,12 @@ go = torch.randn(B, nq, 512, generator=g).bfloat16().to(dev)
 order = K.msda_ref_order(ref0, KS[0])
 refd = ref0[None, :, None, :].expand(B, nq, 4, 2)
 res = {}
-for tag, dis in (('mfma d_value', set()), ('record pipeline', {'msda_value_mm'}))[:1 if os.environ.get('GE_LIB') else 2]:
-    K.DISABLED.clear(); K.DISABLED.update(dis)
+for tag, dis in (('mfma d_value', set()), ('record pipeline', {'msda_value_mm'}), ('per level', {'auto'}))[:1 if os.environ.get('GE_LIB') else 3]:
+    K.DISABLED.clear()
+    K._MM_VALUE_CHOICE.clear()
+    os.environ.pop('GE_MSDA_VALUE', None)
+    if 'auto' not in dis:
+        os.environ['GE_MSDA_VALUE'] = 'records' if dis else 'mm'
     raw = raw0.clone().requires_grad_(True)
     def run():
         value.grad = None
@@ -54,6 +58,8 @@ for tag, dis in (('mfma d_value', set()), ('record pipeline', {'msda_value_mm'})
 if os.environ.get('GE_LIB'):
     sys.exit(0)
 a, b = res['mfma d_value'], res['record pipeline']
+c = res['per level']
+print('per-level choice vs records: max abs diff / scale', ((c - b).abs().max() / b.abs().max()).item(), ' l2 rel', ((c - b).norm() / b.norm()).item())
 print('d_value: max abs diff / scale', ((a - b).abs().max() / b.abs().max()).item(), ' l2 rel', ((a - b).norm() / b.norm()).item())
 # run statistics of the MFMA d_value path: read the workspace back
 import ctypes
@@ -68,7 +74,7 @@ base, dbase = raw.data_ptr(), d_raw.data_ptr()
 hip.check(lib.ge_msda_bwd_lw_mm(value.data_ptr(), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
                                 order.data_ptr(), go.data_ptr(), dbase, ld, dbase + n_off * 2, ld, ws.data_ptr(), B, nv, nq, 8, 4, 8, 1, None), 'lw')
 hip.check(lib.ge_msda_bwd_value_mm(shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
-                                   order.data_ptr(), go.data_ptr(), dv.data_ptr(), ws.data_ptr(), ws_bytes, B, nv, nq, 8, 4, 8, 1, None), 'dv')
+                                   order.data_ptr(), go.data_ptr(), dv.data_ptr(), ws.data_ptr(), ws_bytes, 15, B, nv, nq, 8, 4, 8, 1, None), 'dv')
 torch.cuda.synchronize()
 ntiles, segs = (nq + 31) // 32, B * 8 * 4
 r256 = lambda x: (x + 255) // 256 * 256
@@ -89,6 +95,7 @@ print('runs', tot, 'per level (runs, rows, tiles):', per_level, ' kernel statist
 # the adaptive choice (kernels._MMValueChoice): 40 backward calls, what it settles on
 K.DISABLED.clear()
 K._MM_VALUE_CHOICE.clear()
+os.environ.pop('GE_MSDA_VALUE', None)
 raw = raw0.clone().requires_grad_(True)
 for i in range(40):
     value.grad = None
@@ -96,4 +103,4 @@ for i in range(40):
     if i % 8 == 0: torch.cuda.synchronize()
 torch.cuda.synchronize()
 for k, c in K._MM_VALUE_CHOICE.items():
-    print('choice for', k[:4], ': use_mm', c.use_mm, 'last statistics', c.last)
+    print('choice for', k[:4], ': MFMA kernel on levels', [l for l in range(4) if (c.mm_mask >> l) & 1], 'statistics', c.last)
