@@ -75,6 +75,19 @@ __device__ __forceinline__ Lerp ge_lerp(int dst, int in, float scale, bool align
 
 static inline hipStream_t ge_stream(void* s) { return (hipStream_t)s; }
 
+// Compute-unit count of the CURRENT device, cached per device id (a process may drive several devices; a single cached value would size the
+// persistent grids of every device after the first caller's).  0 on error.
+static inline int ge_cu_count() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev < 64 && __atomic_load_n(&cache[dev], __ATOMIC_RELAXED)) return cache[dev];
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  if (dev < 64) __atomic_store_n(&cache[dev], p.multiProcessorCount, __ATOMIC_RELAXED);
+  return p.multiProcessorCount;
+}
+
 // Dropout masks are a counter-based hash of (seed, element index) with the seed a launch ARGUMENT — frozen when the launch is captured in a
 // hipGraph.  ge_rng_salt(ptr) (neck.hip) registers a device counter that every dropout kernel adds to its seed at EXECUTION time; a
 // captured step increments it inside the graph, so each replay draws fresh masks (forward and backward of one step read the same value).

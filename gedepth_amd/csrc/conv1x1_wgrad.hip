@@ -142,8 +142,8 @@ extern "C" int ge_conv1x1_nhwc_wgrad(const void* x, const void* dy, float* dw, l
   const int ci_chunk = (Cin % 96 == 0) ? 96 : 64;
   const int n_ci = Cin / ci_chunk, n_co = (Cout + C1_MAX_CB * 32 - 1) / (C1_MAX_CB * 32);
   if (n_ci > 65535 || n_co > 65535) return GE_ERR_UNSUPPORTED;
-  static int cus = 0;
-  if (!cus) { hipDeviceProp_t p; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return GE_ERR_BAD_ARG; cus = p.multiProcessorCount; }
+  const int cus = ge_cu_count();                          // per device (common.h)
+  if (!cus) return GE_ERR_BAD_ARG;
   const long nstage = (M + C1_ROWS - 1) / C1_ROWS;
   long ksplit = cus / ((long)n_ci * n_co);                        // ONE resident round (one workgroup per CU), rounded down
   ksplit = std::max(1L, std::min(ksplit, std::min(nstage, 65535L)));

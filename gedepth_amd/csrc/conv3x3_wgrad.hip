@@ -169,8 +169,8 @@ extern "C" int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, i
   // K split: ONE resident round of workgroups (two per CU: 54 KB of LDS each), rounded DOWN.  Every workgroup does the same amount of
   // work, so a grid that exceeds the resident slots by a few workgroups costs a whole extra round: the round-3 rule (~1024 workgroups,
   // rounded up) launched 1026 for 576 -> 64 (18 output blocks x 57) and 1025 for 160 -> 64 (5 x 205) = three rounds where two would do.
-  static int cus = 0;
-  if (!cus) { hipDeviceProp_t p; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return GE_ERR_BAD_ARG; cus = p.multiProcessorCount; }
+  const int cus = ge_cu_count();                          // per device (common.h)
+  if (!cus) return GE_ERR_BAD_ARG;
   long ksplit = (2L * cus) / blocks_out;
   if (ksplit > total) ksplit = total;
   if (ksplit < 1) ksplit = 1;

@@ -321,8 +321,8 @@ extern "C" int ge_gemm_nt(const void* A, long lda, const void* B, long ldb, cons
   const long ntm = (M + GM_BM - 1) / GM_BM;
   if (ntm > (1 << 24)) return GE_ERR_UNSUPPORTED;
   a.ntm = (int)ntm; a.ntn = (N + GM_BN - 1) / GM_BN;
-  static int cus = 0;
-  if (!cus) { hipDeviceProp_t p; int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return GE_ERR_BAD_ARG; cus = p.multiProcessorCount; }
+  const int cus = ge_cu_count();                          // per device (common.h)
+  if (!cus) return GE_ERR_BAD_ARG;
   int grid = cus & ~7; if (grid < 8) grid = 8;              // one persistent workgroup per CU; workgroups without a tile return at once
   const hipStream_t s = ge_stream(stream);
   if (bias) gemm_nt_k<1><<<grid, 512, 0, s>>>(a);

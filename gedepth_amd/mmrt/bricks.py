@@ -123,8 +123,11 @@ def _linear_fwd(xc, wc, weight, bias, dt):
     from .optim import lowp
     K = xc.shape[-1]
     M = xc.numel() // K
+    # ge_gemm_nt wants 16-byte-aligned operands (a contiguous view at an odd storage offset, a bias slice of an arena built with align < 4,
+    # would be refused with GE_ERR_UNSUPPORTED in the middle of training): such calls take the library
     if (dt == torch.bfloat16 and xc.is_cuda and xc.is_contiguous() and wc.is_contiguous() and kernels.gemm_own(M, K, wc.shape[0])
-            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))
+            and xc.data_ptr() % 16 == 0 and wc.data_ptr() % 16 == 0):
         return kernels.gemm_nt(xc.reshape(M, K), wc, None if bias is None else bias.detach()).view(*xc.shape[:-1], wc.shape[0])
     return F.linear(xc, wc, None if bias is None else lowp(bias, dt))
 
@@ -134,7 +137,7 @@ def _linear_dx(dy2, wc):
     from .. import kernels
     M, N = dy2.shape
     K = wc.shape[1]
-    if dy2.dtype == torch.bfloat16 and dy2.is_contiguous() and kernels.gemm_own(M, N, K):
+    if dy2.dtype == torch.bfloat16 and dy2.is_contiguous() and dy2.data_ptr() % 16 == 0 and kernels.gemm_own(M, N, K):
         return kernels.gemm_nt(dy2, wc.t().contiguous(), None)          # (K, N) weight image: <= 1.2 MB, one small transpose kernel
     return dy2 @ wc
 
