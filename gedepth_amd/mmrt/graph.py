@@ -36,6 +36,7 @@ class GraphedTrainStep:
         dev = optimizer.arena.flat_param.device
         self.salt = torch.zeros(1, device=dev, dtype=torch.int64)       # dropout counter, advanced inside the graph
         self._warmup_left = int(warmup)
+        self.disabled = False                    # set when a capture failed: the object then runs every step eagerly
         self.stream = torch.cuda.Stream(dev)                             # warm-up steps and the capture share this side stream
 
     # ---- one step, eager or being captured
@@ -98,9 +99,20 @@ class GraphedTrainStep:
             if self.graph is None and self._warmup_left > 0:
                 self._warmup_left -= 1
                 out = self._step_body()
+            elif self.disabled:
+                out = self._step_body()
             else:
                 if self.graph is None:
-                    self.capture()               # the capture does not execute: replay it for this step
+                    try:
+                        self.capture()           # the capture does not execute: replay it for this step
+                    except Exception as e:       # an op that cannot be captured (a new code path, a library call that synchronises): train eagerly
+                        import warnings
+                        warnings.warn(f'GraphedTrainStep: capture failed ({type(e).__name__}: {e}); continuing with eager steps')
+                        self.disabled, self.graph = True, None
+                        torch.cuda.synchronize()
+                        out = self._step_body()
+                        cur.wait_stream(self.stream)
+                        return out
                 self.graph.replay()
                 self.replays += 1
                 out = self.out
