@@ -771,24 +771,40 @@ __device__ __forceinline__ MvBox mv_join(const MvBox& a, const MvBox& b) {
 // Record (2 x int4): {segment = (image * nH + head) * 4 + level, first tile | tiles << 24, box 0: min y << 16 | min x, height << 16 | width},
 //                    {box 1: min y << 16 | min x, height << 16 | width, -, -}; an empty box has width = height = 0.
 __global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int nsegs, int level_mask) {
+  // runs are collected in LDS and appended to the XCD's list 64 at a time: a slot reservation per run is a global atomic WITH return, ~1 us
+  // of round trip each — with one run per tile (the model's geometry) that was 3 080 serial round trips per wave: 1.27 ms for this kernel
+  __shared__ int4 pend[2 * 64];
   const int seg = blockIdx.x, lane = threadIdx.x;
   const int xcd = (int)(((long)(seg >> 2) * MSDA_XCDS) / (nsegs >> 2));     // image-major: the mapping of the sampling kernels
   const int4* bb = ws.bbox + (long)seg * ntiles;
   int4* list = ws.runs + (long)xcd * ws.runs_cap * 2;
   const MvBox none{32767, 32767, -32768, -32768};
-  int t0 = 0, nrows = 0, npass = 0;
+  const bool wanted = (level_mask >> (seg & 3)) & 1;                         // statistics for every level, work only for the requested ones
+  int t0 = 0, nrows = 0, npass = 0, npend = 0;
   MvBox c0 = none, c1 = none;                                               // current run: union boxes of the two point groups (uniform)
+  auto flush = [&]() {
+    if (npend == 0) return;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(ws.ctrl + xcd, npend);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 2 * npend; i += 64) list[2 * slot + i] = pend[i];
+    __builtin_amdgcn_wave_barrier();
+    npend = 0;
+  };
   auto emit = [&](int t1) {
     const int k0 = mv_rows(c0), k1 = mv_rows(c1);
     if (k0 + k1 > 0 && t1 > t0) {
       nrows += k0 + k1;
       npass += (t1 - t0) * ((k0 + k1 + MV_CAP - 1) / MV_CAP);
-      if (lane == 0 && ((level_mask >> (seg & 3)) & 1)) {         // statistics for every level, work only for the requested ones
-        const int slot = atomicAdd(ws.ctrl + xcd, 1);
-        const bool s0 = k0 > 0, s1 = k1 > 0;
-        list[2 * slot] = make_int4(seg, t0 | ((t1 - t0) << 24), s0 ? (c0.y0 << 16) | (c0.x0 & 0xffff) : 0,
-                                   s0 ? ((c0.y1 - c0.y0 + 1) << 16) | (c0.x1 - c0.x0 + 1) : 0);
-        list[2 * slot + 1] = make_int4(s1 ? (c1.y0 << 16) | (c1.x0 & 0xffff) : 0, s1 ? ((c1.y1 - c1.y0 + 1) << 16) | (c1.x1 - c1.x0 + 1) : 0, 0, 0);
+      if (wanted) {
+        if (lane == 0) {
+          const bool s0 = k0 > 0, s1 = k1 > 0;
+          pend[2 * npend] = make_int4(seg, t0 | ((t1 - t0) << 24), s0 ? (c0.y0 << 16) | (c0.x0 & 0xffff) : 0,
+                                      s0 ? ((c0.y1 - c0.y0 + 1) << 16) | (c0.x1 - c0.x0 + 1) : 0);
+          pend[2 * npend + 1] = make_int4(s1 ? (c1.y0 << 16) | (c1.x0 & 0xffff) : 0, s1 ? ((c1.y1 - c1.y0 + 1) << 16) | (c1.x1 - c1.x0 + 1) : 0, 0, 0);
+        }
+        if (++npend == 64) flush();
       }
     }
   };
@@ -807,6 +823,7 @@ __global__ void __launch_bounds__(64) msda_mm_runs_k(MvWs ws, int ntiles, int ns
     }
   }
   emit(ntiles);
+  flush();
   if (lane == 0 && nrows) {
     atomicAdd(ws.ctrl + 16, nrows); atomicAdd(ws.ctrl + 17, npass);
     atomicAdd(ws.ctrl + 18 + 2 * (seg & 3), nrows); atomicAdd(ws.ctrl + 19 + 2 * (seg & 3), npass);      // the same per level

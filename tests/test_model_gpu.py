@@ -875,10 +875,79 @@ def test_linear_weight_gradients_are_written_into_the_arena(dev):
     print(f'\n[arena-direct gradients] {len(direct)} tensors, {elems / 1e6:.1f} M of {opt.arena.numel / 1e6:.1f} M elements: e.g. {big[:3]}')
     assert any('attn.w_msa.qkv.weight' in n for n in direct) and any('ffn.layers.1.weight' in n for n in direct) and any('decode_head.conv_list' in n for n in direct), direct[:10]
     assert elems >= 0.9 * opt.arena.numel, (elems, opt.arena.numel)        # Linear (split-K and plain) and convolution weights; what is left are biases / norms
-    # two runs of one step differ by the order of the fp32 atomics upstream (the earliest backbone layers, sums of cancelling terms, by up to
-    # ~2 %): per tensor 5 %, all of them together 1 %
-    for n in direct:
-        a, b = g_new[n].double(), g_old[n].double()
-        assert (a - b).norm() <= 5e-2 * b.norm() + 1e-12, (n, ((a - b).norm() / b.norm()).item())
-    A, B = torch.cat([g_new[n].double().flatten() for n in direct]), torch.cat([g_old[n].double().flatten() for n in direct])
-    assert ((A - B).norm() / B.norm()).item() <= 1e-2
+    # VALUES: two runs of a whole step differ by the order of fp32 atomics upstream (and this batch has the heavy-tailed loss gradient of
+    # single tensors moved by 2 - 20 % between identical runs), so the two paths are compared where nothing upstream is noisy — one
+    # token Linear (split-K and plain), one library convolution and one MFMA 3x3 convolution, each alone: bit-identical
+    from gedepth_amd.mmrt import bricks
+    from gedepth_amd.mmrt.optim import GradArena
+    torch.manual_seed(1)
+    lin_big, lin_small = bricks.Linear(96, 192).to(dev), bricks.Linear(96, 192).to(dev)
+    conv1, conv3 = bricks.ConvModule(64, 96, 1, act_cfg=None).to(dev), bricks.ConvModule(64, 64, 3, padding=1, act_cfg=dict(type='LeakyReLU')).to(dev)
+    for m in (conv1, conv3):
+        m.to(memory_format=torch.channels_last)
+    params = [lin_big.weight, lin_small.weight, conv1.conv.weight, conv3.conv.weight]
+    arena = GradArena([p for m in (lin_big, lin_small, conv1, conv3) for p in m.parameters()])
+    xb, xs = torch.randn(4, 4096, 96, device=dev), torch.randn(2, 300, 96, device=dev)
+    xc = torch.randn(2, 64, 120, 160, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def small():
+        arena.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            loss = lin_big(xb).float().square().mean() + lin_small(xs).float().square().mean() + conv1(xc).float().square().mean() + conv3(xc).float().square().mean()
+        loss.backward()
+        hit = [p.grad is not None and p.grad.data_ptr() == p._ge_grad_view.data_ptr() if p._ge_grad_view is not None else False for p in params]
+        arena.collect()
+        return hit, [p.grad.detach().clone() for p in params]
+    hit, g1 = small()
+    assert all(hit), hit
+    keep = [p._ge_grad_view for p in arena.params]
+    for p in arena.params:
+        p._ge_grad_view = None
+    hit0, g0 = small()
+    for p, v in zip(arena.params, keep):
+        p._ge_grad_view = v
+    assert not any(hit0)
+    for i, (a_, b_, p) in enumerate(zip(g1, g0, params)):
+        if i < 3:
+            assert torch.equal(a_, b_), (tuple(p.shape), (a_ - b_).abs().max().item())
+        else:                                   # the MFMA 3x3 weight gradient flushes its K-split partials with fp32 atomics: order-dependent last bits
+            assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-6 * b_.abs().max().item()), (tuple(p.shape), (a_ - b_).abs().max().item())
+
+
+def test_runner_with_hip_graph_trains_like_the_eager_runner(dev, tmp_path):
+    """``IterBasedRunner(hip_graph=True)`` (what ``tools/train.py --hip-graph`` builds): the hot loop with LR hook, logger hook and the captured
+    step — 3 eager iterations, capture, replays on loader batches copied into the static buffers; the optimizer hook steps aside.  Against
+    the eager runner on the same loader and seeds: the learning rate schedule reaches the device (first and last logged lr equal), the
+    logged losses agree, the step counter advanced once per iteration."""
+    from gedepth_amd.depth.datasets.loader import SyntheticKITTI
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.optim import build_optimizer
+    from gedepth_amd.mmrt.runner import IterBasedRunner
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_a.py'))
+    data = SyntheticKITTI(8, 128, 160, adaptive=True, seed=5)
+    from gedepth_amd.depth.datasets.loader import build_dataloader
+    results = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        model = build('depthformer_swint_a.py')
+        load_filled(model, 'runner_graph')
+        model = model.to(dev).train()
+        opt = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+        logs = []
+        runner = IterBasedRunner(model, opt, work_dir=str(tmp_path / f'g{int(mode)}'), logger=logs.append, max_iters=8, amp_dtype=torch.bfloat16,
+                                 hip_graph=mode)
+        runner.register_training_hooks(dict(policy='CosineAnnealing', min_lr_ratio=1e-2, warmup='linear', warmup_iters=4, warmup_ratio=0.1, by_epoch=False),
+                                       dict(grad_clip=cfg.optimizer_config.get('grad_clip')), None, dict(interval=2, hooks=[dict(type='TextLoggerHook')]))
+        loader = build_dataloader(data, 2, 0, dist=False, seed=3, shuffle=False, drop_last=True)
+        runner.run([loader])
+        torch.cuda.synchronize()
+        assert runner.iter == 8 and opt.step_count == 8
+        if mode:
+            assert runner.graphed is not None and runner.graphed.graph is not None and runner.graphed.replays == 5
+            runner.graphed.release()
+        results[mode] = dict(lr=runner.current_lr, loss=float(runner.outputs['log_vars']['loss']),
+                             params=torch.cat([p.detach().float().flatten() for p in model.parameters()]))
+    assert results[False]['lr'] == results[True]['lr']
+    a, b = results[False], results[True]
+    assert abs(a['loss'] - b['loss']) <= 1e-2 * abs(a['loss']), (a['loss'], b['loss'])
+    print(f'\n[runner hip_graph] last loss eager {a["loss"]:.5f} graph {b["loss"]:.5f}')
