@@ -908,9 +908,10 @@ def test_linear_weight_gradients_are_written_into_the_arena(dev):
         p._ge_grad_view = v
     assert not any(hit0)
     for i, (a_, b_, p) in enumerate(zip(g1, g0, params)):
-        if i < 3:
+        if i < 2:
             assert torch.equal(a_, b_), (tuple(p.shape), (a_ - b_).abs().max().item())
-        else:                                   # the MFMA 3x3 weight gradient flushes its K-split partials with fp32 atomics: order-dependent last bits
+        else:                                   # the MFMA 3x3 weight gradient flushes its K-split partials with fp32 atomics, and the library's 1x1
+            # weight gradient (MIOpen picks a split-K solver with atomics when the find-db has been warmed by earlier tests): order-dependent last bits
             assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-6 * b_.abs().max().item()), (tuple(p.shape), (a_ - b_).abs().max().item())
 
 
