@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-inline-asm $*"
-SRCS="aug.hip conv3x3.hip conv3x3_c1.hip conv3x3_wgrad.hip conv1x1_wgrad.hip decoder.hip gemm.hip ground.hip msda.hip msda_drain_mfma.hip msda_mm.hip msda_win.hip neck.hip nhwc.hip norm.hip window_attn.hip window_attn_mfma.hip"
+SRCS="aug.hip conv3x3.hip conv3x3_c1.hip conv3x3_wgrad.hip conv1x1_wgrad.hip conv1x1_bn.hip decoder.hip gemm.hip ground.hip msda.hip msda_drain_mfma.hip msda_mm.hip msda_win.hip neck.hip nhwc.hip norm.hip window_attn.hip window_attn_mfma.hip"
 mkdir -p build
 echo "$FLAGS" > build/.flags.new
 if ! cmp -s build/.flags.new build/.flags 2>/dev/null; then rm -f build/*.o; mv build/.flags.new build/.flags; else rm -f build/.flags.new; fi

@@ -107,11 +107,13 @@ class MultiScaleDeformableAttention(BaseModule):
             return residual_dropout(identity, out, self.dropout.p)
         return self.dropout(out) + identity
 
-    def forward_map(self, fmap, pos_map, value, reference_points, spatial_shapes, concat_with, query_order=None):
+    def forward_map(self, fmap, pos_map, value, reference_points, spatial_shapes, concat_with, query_order=None, query=None):
         """Cross-attention with a feature-map query (hahi.py:303-333): query = tokens(fmap) + pos, identity = fmap, and the
         result returned as ``torch.cat([to_map(dropout(out) + identity), concat_with], 1)``.  The two layout changes carry
-        the position add, the dropout, the residual and the concat write (gedepth_amd/csrc/neck.hip)."""
-        query = tokens_from_map(fmap, pos_map)
+        the position add, the dropout, the residual and the concat write (gedepth_amd/csrc/neck.hip).  ``query``: tokens(fmap) + pos
+        when the producer of ``fmap`` wrote it in the same pass (kernels.conv1x1_bn_act_pos)."""
+        if query is None:
+            query = tokens_from_map(fmap, pos_map)
         out = self._attend(query, value, reference_points, spatial_shapes, query_shapes=[tuple(fmap.shape[2:])], query_order=query_order)
         p = self.dropout.p if self.training else 0.0
         return concat_tokens_map(out, concat_with, identity=fmap, tokens_first=True, p_drop=p)
@@ -223,10 +225,16 @@ class HAHIHeteroNeck(BaseModule):
         else:
             src = src_flatten
 
-        conv_skip = self.conv_proj(feat_conv)
-        _, c, h, w = conv_skip.shape
+        h, w = feat_conv.shape[2:]
+        pos_map = self.conv_positional_encoding.grid(h, w, dev) if self.cross_att else None      # (1, C, h, w) fp32, cached
+        query = None
+        if self.training and len(self.conv_proj) == 1 and K.conv1x1_bn_act_pos_ok(self.conv_proj[0], feat_conv):
+            # 64 -> E channels at the finest level: convolution, BatchNorm (statistics from the input's Gram matrix), ReLU and the query's
+            # position add in ONE pass over the 8x wider output (csrc/conv1x1_bn.hip); the pre-BN map is never stored
+            conv_skip, query = K.conv1x1_bn_act_pos(self.conv_proj[0], feat_conv, pos_map)
+        else:
+            conv_skip = self.conv_proj(feat_conv)
         if self.cross_att:
-            pos_map = self.conv_positional_encoding.grid(h, w, dev)                     # (1, C, h, w) fp32, cached
             # content-independent reference points: one fp32 (1, Nq, 2) evaluation, broadcast over batch and levels
             with torch.autocast('cuda', enabled=False):
                 # Linear(512 -> 2) over 1e5 positions: as a GEMM with N = 2 the libraries reach ~1 TFLOP/s (0.3 ms, and
@@ -236,7 +244,7 @@ class HAHIHeteroNeck(BaseModule):
                 ref = torch.stack((torch.mv(pm.t(), w[0]), torch.mv(pm.t(), w[1])), -1).add(b).sigmoid()[None]
             order = self._cross_order(ref[0], shapes[0]) if (conv_skip.is_cuda and src.dtype == torch.bfloat16) else None
             ref = ref[:, :, None, :].expand(bs, -1, len(shapes), 2)
-            fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv, query_order=order)
+            fused = self.multi_att.forward_map(conv_skip, pos_map, src, ref, shapes, concat_with=feat_conv, query_order=order, query=query)
         else:
             fused = torch.cat([conv_skip, feat_conv], dim=1)
         # one split (backward: ONE concatenating write of the level gradients) instead of per-level slices, whose backward

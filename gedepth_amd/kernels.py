@@ -1504,6 +1504,117 @@ def bn_act(x, bn, slope=0.0):
     return y
 
 
+# ------------------------------------------------- 1x1 conv + batch norm (training) + ReLU + position add, one pass (csrc/conv1x1_bn.hip)
+class _Conv1x1BNActPos(torch.autograd.Function):
+    """``y = act(bn(conv1x1(x)))`` and ``q = tokens(y) + pos`` for a 64-channel channels-last bf16 map (HAHI ``conv_proj`` and the cross-attention
+    query, reference necks/hahi.py:151-157,294-306).  BatchNorm statistics come from the input's Gram matrix, the pre-BN tensor is never stored;
+    the backward takes the two gradients (through y — possibly a channel slice of a wider map, read in place — and through q) in one masking
+    pass and reduces the BatchNorm backward to rank-64 corrections of the convolution's two gradient GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, pos_rows, eps, momentum, slope):
+        from .mmrt.optim import lowp
+        lib = hip.lib()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        HW, rows = H * W, B * H * W
+        wc = lowp(weight, torch.bfloat16).detach().reshape(Cout, Cin)
+        g32, b32 = _c(gamma.detach().to(_f32)), _c(beta.detach().to(_f32))
+        dev = x.device
+        ws = torch.empty(int(lib.ge_conv1x1_bn_workspace(Cin, Cout)), device=dev, dtype=torch.uint8)
+        gram = torch.empty(65 * Cin, device=dev, dtype=torch.float64)
+        stats = torch.empty(2, Cout, device=dev, dtype=_f32)
+        coef = torch.empty(2, Cout, device=dev, dtype=_f32)
+        y = torch.empty((B, Cout, H, W), device=dev, dtype=x.dtype, memory_format=_CL)
+        q = torch.empty(B, HW, Cout, device=dev, dtype=x.dtype) if pos_rows is not None else None
+        PROFILER.run(f'conv1x1_bn_stats[{B}x{Cin}->{Cout} {H}x{W}]', x.numel() * 2, lambda: hip.check(lib.ge_conv1x1_bn_stats(
+            _raw_ptr(x, 'x'), rows, Cin, hip.ptr(wc), Cout, hip.ptr(g32), hip.ptr(b32), hip.ptr(running_mean, _f32), hip.ptr(running_var, _f32),
+            eps, momentum, hip.ptr(gram), hip.ptr(stats[0]), hip.ptr(stats[1]), hip.ptr(coef), hip.ptr(ws), hip.stream()), 'ge_conv1x1_bn_stats'))
+        PROFILER.run(f'conv1x1_bn_act_fwd[{B}x{Cin}->{Cout} {H}x{W}{" +pos" if q is not None else ""}]',
+                     x.numel() * 2 + y.numel() * 2 * (1 + (q is not None)) + (HW * Cout * 4 if q is not None else 0), lambda: hip.check(
+            lib.ge_conv1x1_bn_act_fwd(_raw_ptr(x, 'x'), hip.ptr(wc), hip.ptr(coef), hip.ptr(pos_rows, _f32), _raw_ptr(y, 'y'), hip.ptr(q), B, HW, Cin, Cout,
+                                      slope, hip.stream()), 'ge_conv1x1_bn_act_fwd'))
+        ctx.save_for_backward(x, wc, g32, stats, gram, y)
+        ctx.meta = (slope, weight.dtype, gamma.dtype, beta.dtype)
+        ctx.weight_ref = weight if isinstance(weight, torch.nn.Parameter) else None
+        if q is None:
+            return y
+        return y, q
+
+    @staticmethod
+    def backward(ctx, dy, dq=None):
+        x, wc, g32, stats, gram, y = ctx.saved_tensors
+        slope, w_dtype, g_dtype, b_dtype = ctx.meta
+        lib = hip.lib()
+        B, Cin, H, W = x.shape
+        Cout = wc.shape[0]
+        rows = B * H * W
+        dev = x.device
+        ld_y = 0
+        if dy is not None:
+            dy = dy.to(x.dtype)
+            # a channel slice of a wider channels-last map (the concat's gradient) is read where it lies: rows of Cout channels, row stride ld
+            ld_y = dy.stride(3)
+            if not (dy.stride(1) == 1 and ld_y >= Cout and ld_y % 8 == 0 and dy.stride(2) == W * ld_y and dy.stride(0) == H * W * ld_y and dy.data_ptr() % 16 == 0):
+                dy, ld_y = _cl(dy), Cout
+        if dq is not None:
+            dq = _c(dq.to(x.dtype))
+        if dy is None and dq is None:
+            return (None,) * 10
+        ws = torch.empty(int(lib.ge_conv1x1_bn_workspace(Cin, Cout)), device=dev, dtype=torch.uint8)
+        g = torch.empty(rows, Cout, device=dev, dtype=x.dtype)
+        m1 = torch.empty(Cout, device=dev, dtype=_f32)
+        PROFILER.run(f'conv1x1_bn_bwd_mask[{B}x{Cout} {H}x{W}]', g.numel() * 2 * (2 + (dy is not None) + (dq is not None)), lambda: hip.check(
+            lib.ge_conv1x1_bn_bwd_mask(hip.ptr(dq), Cout, None if dy is None else _raw_ptr(dy, 'dy'), ld_y, _raw_ptr(y, 'y'), hip.ptr(g), hip.ptr(m1),
+                                       hip.ptr(ws), rows, Cout, slope, hip.stream()), 'ge_conv1x1_bn_bwd_mask'))
+        GT = torch.zeros(Cout, Cin, device=dev, dtype=_f32)
+        PROFILER.run(f'conv1x1_wgrad[{B}x{Cin}->{Cout} {H}x{W}]', (x.numel() + g.numel()) * 2 + GT.numel() * 4, lambda: hip.check(
+            lib.ge_conv1x1_nhwc_wgrad(_raw_ptr(x, 'x'), hip.ptr(g), hip.ptr(GT), rows, Cin, Cout, hip.GE_BF16, hip.stream()), 'ge_conv1x1_nhwc_wgrad'))
+        small = torch.empty(2 * Cout + Cout * Cin + 2 * Cout, device=dev, dtype=_f32)
+        dgamma, dbeta, dW, scratch = small[:Cout], small[Cout:2 * Cout], small[2 * Cout:2 * Cout + Cout * Cin].view(Cout, Cin), small[2 * Cout + Cout * Cin:]
+        ops = torch.empty(Cout * Cin + Cin * Cin + Cin, device=dev, dtype=x.dtype)
+        A1, A2, c0 = ops[:Cout * Cin].view(Cout, Cin), ops[Cout * Cin:Cout * Cin + Cin * Cin].view(Cin, Cin), ops[Cout * Cin + Cin * Cin:]
+        hip.check(lib.ge_conv1x1_bn_bwd_finalize(hip.ptr(GT), hip.ptr(m1), hip.ptr(gram), hip.ptr(wc), hip.ptr(g32), hip.ptr(stats[0]), hip.ptr(stats[1]),
+                                                 rows, Cin, Cout, hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dW), hip.ptr(A1), hip.ptr(A2), hip.ptr(c0),
+                                                 hip.ptr(scratch), hip.stream()), 'ge_conv1x1_bn_bwd_finalize')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            x2 = x.permute(0, 2, 3, 1).reshape(rows, Cin)
+            dx2 = torch.addmm(c0, x2, A2)                      # the rank-64 corrections of the BatchNorm backward ...
+            dx2.addmm_(g, A1)                                  # ... + the convolution's data gradient with the scale folded into the weights
+            dx = dx2.view(B, H, W, Cin).permute(0, 3, 1, 2)
+        dw = dW.view(Cout, Cin, 1, 1)
+        if ctx.weight_ref is not None:
+            from .mmrt.optim import grad_into_arena
+            dw = grad_into_arena(ctx.weight_ref, dw, w_dtype)
+        else:
+            dw = dw.to(w_dtype)
+        return dx, dw, dgamma.to(g_dtype), dbeta.to(b_dtype), None, None, None, None, None, None
+
+
+def conv1x1_bn_act_pos_ok(block, x):
+    """The fused 1x1-conv + BatchNorm + ReLU (+ position add) kernels apply to ConvModule ``block`` on input ``x``: training-mode BatchNorm2d,
+    bf16 autocast, a 64-channel channels-last bf16 map, output width a multiple of 128, no conv bias (csrc/conv1x1_bn.hip).  GE_DISABLE=conv1x1_bn
+    keeps the two-pass kernels (which the fp32 parity mode always uses)."""
+    conv, bn = block.conv, block.norm
+    return ('conv1x1_bn' not in DISABLED and x.is_cuda and x.dtype == torch.bfloat16 and type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1)
+            and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.in_channels == 64
+            and conv.out_channels % 128 == 0 and conv.out_channels <= 2048 and conv.weight.dtype == _f32
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and block._fused_bn_slope() is not None and _is_cl(x) and x.data_ptr() % 16 == 0)
+
+
+def conv1x1_bn_act_pos(block, x, pos=None):
+    """-> (act(bn(conv(x))) as a channels-last map, tokens of it + ``pos`` as (B, H*W, C) or None) in one pass over the output; ``pos``: the cached
+    (1, C, H, W) fp32 positional map.  Caller checks ``conv1x1_bn_act_pos_ok`` first."""
+    bn = block.norm
+    slope = float(block._fused_bn_slope())
+    pos_rows = _pos_rows(pos) if pos is not None else None
+    out = _Conv1x1BNActPos.apply(x, block.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, pos_rows, float(bn.eps), float(bn.momentum), slope)
+    bn.num_batches_tracked.add_(1)
+    return out if pos is not None else (out, None)
+
+
 # ------------------------------------------------------------------------- bias + activation
 class _BiasAct(torch.autograd.Function):
 

@@ -37,7 +37,8 @@ enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
 /* Library / device identification: returns the ABI version (3: round 3 added the raw-projection deformable-attention entry points,
  * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline; 4: round 4 added the MFMA
  * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw), the token GEMM ge_gemm_nt and ge_conv1x1_nhwc_wgrad;
- * 5: round 5 — ge_msda_bwd_lw_mm takes a workspace, ge_msda_bwd_value_mm / ge_msda_bwd_mm_workspace added). */
+ * 5: round 5 — ge_msda_bwd_lw_mm takes a workspace, ge_msda_bwd_value_mm / ge_msda_bwd_mm_workspace added; 6: the fused
+ * 1x1-convolution + BatchNorm + ReLU + position-add entry points ge_conv1x1_bn_*). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -439,6 +440,29 @@ int ge_conv3x3_nhwc_wgrad(const void* x, const void* dy, float* dw, int N, int H
  * of necks/hahi.py:120-166): dw (Cout, Cin) fp32 += dy^T x over the M = N H W rows; x (M, Cin), dy (M, Cout) row-major; the CALLER zero-fills
  * dw.  Cin % 64 == 0 or Cin % 96 == 0, Cout % 32 == 0, dtype GE_BF16. */
 int ge_conv1x1_nhwc_wgrad(const void* x, const void* dy, float* dw, long M, int Cin, int Cout, int dtype, void* stream);
+/* 1x1 convolution + training-mode BatchNorm2d + (Leaky)ReLU [+ positional embedding] of a 64-channel channels-last bf16 map in one pass
+ * over the output (csrc/conv1x1_bn.hip) — the conv_proj ConvModule of the HAHI neck and the cross-attention query built from it (reference
+ * depth/models/necks/hahi.py:151-157 and :294-306: query = flatten(conv_proj(x)) + pos).  The BatchNorm batch statistics of z = x W^T are
+ * derived from the moments of the INPUT (mean_c = w_c . m, E[z_c^2] = w_c^T S w_c), so z is never stored.  Cin == 64, Cout % 128 == 0.
+ *   ge_conv1x1_bn_workspace  bytes of the scratch buffer the stats / mask calls need (0: unsupported widths).
+ *   ge_conv1x1_bn_stats      x (rows, 64) bf16, w (Cout, 64) bf16 -> gram (65 * 64 doubles: sum x x^T | sum x, kept for the backward),
+ *                            save_mean / save_rstd (Cout), coef (2 Cout: scale | shift); running statistics updated like F.batch_norm (or NULL).
+ *   ge_conv1x1_bn_act_fwd    y (B * HW, Cout) bf16 = act(coef_a * (x W^T) + coef_b); q = y + pos[p] (pos (HW, Cout) fp32; q and pos NULL together).
+ *   ge_conv1x1_bn_bwd_mask   g (rows, C) bf16 = (dy1 + dy2) * act'(y) and its column sums; dy1 / dy2 bf16 with row strides ld1 / ld2 (elements),
+ *                            either may be NULL — a gradient that arrives as a channel slice of a wider map is read in place.
+ *   ge_conv1x1_bn_bwd_finalize  from GT = g^T x ((Cout, 64) fp32: ge_conv1x1_nhwc_wgrad), the column sums and gram: d_gamma, d_beta, dW (Cout, 64)
+ *                            fp32, and the operands of dX = g A1 + x A2 + c0 (A1 (Cout, 64), A2 (64, 64), c0 (64), all bf16); scratch 2 Cout floats. */
+size_t ge_conv1x1_bn_workspace(int Cin, int Cout);
+int ge_conv1x1_bn_stats(const void* x, long rows, int Cin, const void* w, int Cout, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float eps, float momentum, double* gram, float* save_mean, float* save_rstd, float* coef,
+                        void* workspace, void* stream);
+int ge_conv1x1_bn_act_fwd(const void* x, const void* w, const float* coef, const float* pos, void* y, void* q, int B, long HW, int Cin, int Cout,
+                          float slope, void* stream);
+int ge_conv1x1_bn_bwd_mask(const void* dy1, long ld1, const void* dy2, long ld2, const void* y, void* g, float* colsum, void* workspace, long rows,
+                           int C, float slope, void* stream);
+int ge_conv1x1_bn_bwd_finalize(const float* GT, const float* colsum, const double* gram, const void* w, const float* gamma, const float* save_mean,
+                               const float* save_rstd, long rows, int Cin, int Cout, float* dgamma, float* dbeta, float* dW, void* A1, void* A2,
+                               void* c0, float* scratch, void* stream);
 /* The same layer with ONE output channel (csrc/conv3x3_c1.hip): the depth regressor `conv_depth` (reference
  * depth/models/decode_heads/decode_head.py: nn.Conv2d(channels, 1, 3, padding=1)) and `convfinal` of the ground-attention neck
  * (necks/pemask_neck.py:36-42): a streaming reduction on the vector pipe (v_dot2c_f32_bf16), not a GEMM with N = 1.

@@ -1152,6 +1152,70 @@ def test_bn_act_training(dev, shape, slope, dtype):
         close_scaled(bn.bias.grad, ref_bn.bias.grad, what='dbeta')
 
 
+@pytest.mark.parametrize('shape,cout,mode', [((2, 64, 24, 40), 512, 'both'), ((3, 64, 7, 9), 256, 'both'), ((2, 64, 16, 20), 128, 'map'),
+                                             ((1, 64, 33, 17), 512, 'tokens'), ((2, 64, 24, 40), 512, 'slice')])
+def test_conv1x1_bn_act_pos_vs_fp32_composition(dev, shape, cout, mode):
+    """csrc/conv1x1_bn.hip: ConvModule(64 -> Cout, 1x1, BN, ReLU) + the query's position add (reference necks/hahi.py:151-157,294-306) in one pass,
+    BatchNorm statistics from the input's Gram matrix — against conv2d -> batch_norm(training) -> relu -> + pos in fp32 on the same bf16 inputs
+    and bf16-rounded weights: both outputs, running statistics, and all four gradients (the BatchNorm backward is rank-64 algebra there, see the
+    file header).  ``slice``: the gradient of the map arrives as a channel slice of a wider channels-last map (torch.cat backward) and is read
+    in place; ``map`` / ``tokens``: only one of the two outputs is used."""
+    from gedepth_amd import kernels as K
+    from gedepth_amd.mmrt.bricks import ConvModule
+    g = gen(77)
+    B, Cin, H, W = shape
+    block = ConvModule(Cin, cout, 1, norm_cfg=dict(type='BN', requires_grad=True), act_cfg=dict(type='ReLU'))
+    with torch.no_grad():
+        block.conv.weight.copy_(torch.randn(cout, Cin, 1, 1, generator=g) * 0.2)
+        block.bn.weight.copy_(torch.rand(cout, generator=g) + 0.5); block.bn.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+        block.bn.running_mean.copy_(torch.randn(cout, generator=g)); block.bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    import copy
+    ref = copy.deepcopy(block)
+    block = block.to(dev).train()
+    x = (torch.relu(torch.randn(*shape, generator=g)) * 1.3 + 0.1).to(torch.bfloat16)            # post-ReLU statistics: mean comparable to the deviation
+    pos = torch.randn(1, cout, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g).to(torch.bfloat16)
+    gq = torch.randn(B, H * W, cout, generator=g).to(torch.bfloat16)
+    extra = torch.randn(B, 32, H, W, generator=g).to(torch.bfloat16)
+    # ---- fp32 composition on the CPU
+    xr = x.float().clone().requires_grad_(True)
+    wr = ref.conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    z = F.conv2d(xr, wr)
+    yr = F.relu(F.batch_norm(z, ref.bn.running_mean, ref.bn.running_var, ref.bn.weight, ref.bn.bias, True, ref.bn.momentum, ref.bn.eps))
+    qr = yr.flatten(2).transpose(1, 2) + pos.flatten(2).transpose(1, 2)
+    loss = 0
+    if mode != 'tokens':
+        loss = loss + (yr * gy.float()).sum()
+    if mode != 'map':
+        loss = loss + (qr * gq.float()).sum()
+    loss.backward()
+    # ---- the fused kernels
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert K.conv1x1_bn_act_pos_ok(block, xg)
+        y, q = K.conv1x1_bn_act_pos(block, xg, pos.to(dev))
+    assert y.dtype == q.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    out = 0
+    if mode == 'slice':
+        wide = torch.cat([y, extra.to(dev).contiguous(memory_format=torch.channels_last)], 1)
+        out = out + (wide.float() * torch.cat([gy, torch.zeros_like(extra)], 1).to(dev).float()).sum()
+    elif mode != 'tokens':
+        out = out + (y.float() * gy.to(dev).float()).sum()
+    if mode != 'map':
+        out = out + (q.float() * gq.to(dev).float()).sum()
+    out.backward()
+    close(y.float(), yr, rtol=2 ** -7, atol=2 ** -7, what='y')
+    close(q.float(), qr, rtol=2 ** -7, atol=2 ** -6, what='q')
+    close(block.bn.running_mean, ref.bn.running_mean, rtol=1e-4, atol=1e-5, what='running_mean')
+    close(block.bn.running_var, ref.bn.running_var, rtol=1e-4, atol=1e-5, what='running_var')
+    assert int(block.bn.num_batches_tracked) == 1
+    # gradients: the masked gradient g is stored in bf16 (as the two-pass path stores dy), relu'(y) flips where |y| is at rounding level
+    errs = dict(dx=l2rel(xg.grad.float(), xr.grad), dw=l2rel(block.conv.weight.grad, wr.grad), dgamma=l2rel(block.bn.weight.grad, ref.bn.weight.grad),
+                dbeta=l2rel(block.bn.bias.grad, ref.bn.bias.grad))
+    print(f'\n[conv1x1_bn {shape}->{cout} {mode}] l2 errors', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert errs['dx'] <= 1e-2 and errs['dw'] <= 6e-3 and errs['dgamma'] <= 6e-3 and errs['dbeta'] <= 6e-3, errs
+
+
 @pytest.mark.gpu
 def test_conv_module_bn_relu_fused_matches_unfused(dev):
     from gedepth_amd.mmrt.bricks import ConvModule

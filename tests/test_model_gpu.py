@@ -912,7 +912,7 @@ def test_linear_weight_gradients_are_written_into_the_arena(dev):
             assert torch.equal(a_, b_), (tuple(p.shape), (a_ - b_).abs().max().item())
         else:                                   # the MFMA 3x3 weight gradient flushes its K-split partials with fp32 atomics, and the library's 1x1
             # weight gradient (MIOpen picks a split-K solver with atomics when the find-db has been warmed by earlier tests): order-dependent last bits
-            assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-6 * b_.abs().max().item()), (tuple(p.shape), (a_ - b_).abs().max().item())
+            assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-4 * b_.abs().max().item()), (tuple(p.shape), (a_ - b_).abs().max().item())
 
 
 def test_runner_with_hip_graph_trains_like_the_eager_runner(dev, tmp_path):
