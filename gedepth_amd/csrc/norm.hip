@@ -303,6 +303,23 @@ extern "C" int ge_layernorm_bwd_multi(const void* dy, int y_dtype, const void* x
   return GE_ERR_UNSUPPORTED;
 }
 
+// The caller's reduction of ge_layernorm_bwd_multi's accumulator copies, leaving them ZERO again: out[i] = sum_k dgb[k][i], dgb[k][i] = 0 for
+// i < 2 C.  With a persistent, initially zeroed accumulator buffer per width a LayerNorm backward is two launches (kernel + fold) instead of
+// zero-fill + kernel + sum.
+__global__ void __launch_bounds__(256) layernorm_fold_k(float* __restrict__ dgb, float* __restrict__ out, int copies, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int k = 0; k < copies; ++k) { a += dgb[(long)k * n + i]; dgb[(long)k * n + i] = 0.f; }
+  out[i] = a;
+}
+extern "C" int ge_layernorm_fold(float* dgb, float* out, int copies, int C, void* stream) {
+  if (!dgb || !out || copies < 1 || copies > 64 || C <= 0) return GE_ERR_BAD_ARG;
+  layernorm_fold_k<<<(2 * C + 255) / 256, 256, 0, ge_stream(stream)>>>(dgb, out, copies, 2 * C);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
 // ============================================================================ BatchNorm2d (training) + ReLU, NCHW
 // conv -> BN -> ReLU of mmcv ConvModule (necks/hahi.py:150-166 lateral / proj / fusion convs, depthformer_swin.py:1127-1139
 // stem).  MIOpen's spatial BN plus ATen's clamp / threshold_backward make four kernels and ~10 passes over the map; here:

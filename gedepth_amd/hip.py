@@ -53,6 +53,7 @@ SIGNATURES = {
     'ge_layernorm_bwd': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     'ge_layernorm_bwd_res': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp]),
     'ge_layernorm_bwd_multi': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp]),
+    'ge_layernorm_fold': (_i, [_vp, _vp, _i, _i, _vp]),
     'ge_residual_scale_add': (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _l, _vp]),
     'ge_scale_rows': (_i, [_vp, _i, _vp, _vp, _i, _i, _l, _vp]),
     'ge_bn_workspace': (_sz, [_i]),

@@ -1234,6 +1234,25 @@ def upsum(fine, coarse_maps, align_corners=True):
 _LN_COPIES = max(1, min(64, int(os.environ.get('GE_LN_COPIES', '8'))))      # accumulators of the d_gamma / d_beta column sums (same-address fp32 atomics serialise in L2)
 
 
+_LN_ACC = {}
+
+
+def _ln_accumulators(device, C):
+    """The (copies, 2, C) fp32 accumulators of a LayerNorm backward: one persistent buffer per (device, stream, width), zero on entry — the fold
+    kernel that sums the copies clears them again (ge_layernorm_fold), so no zero-fill launch per layer.  Launches are stream-ordered."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, C)
+    buf = _LN_ACC.get(key)
+    if buf is None:
+        buf = _LN_ACC[key] = torch.zeros(_LN_COPIES, 2, C, device=device, dtype=_f32)
+    return buf
+
+
+def _ln_fold(dwb, C):
+    out = torch.empty(2, C, device=dwb.device, dtype=_f32)
+    hip.check(hip.lib().ge_layernorm_fold(hip.ptr(dwb), hip.ptr(out), _LN_COPIES, C, hip.stream()), 'ge_layernorm_fold')
+    return out
+
+
 class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
@@ -1261,12 +1280,12 @@ class _LayerNorm(torch.autograd.Function):
         if dy.dtype not in (_f32, torch.bfloat16):
             dy = dy.to(_f32)
         dx = torch.empty_like(x)
-        dwb = torch.zeros(_LN_COPIES, 2, C, device=x.device, dtype=_f32)                       # see ge_layernorm_bwd_multi
+        dwb = _ln_accumulators(x.device, C)                                                    # see ge_layernorm_bwd_multi
         PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}]', 2 * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
             hip.lib().ge_layernorm_bwd_multi(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
                                              hip.ptr(rstd), None, hip.ptr(dx), hip.ptr(dwb), _LN_COPIES, rows, C, hip.stream()),
             'ge_layernorm_bwd_multi'))
-        dwb = dwb.sum(0)
+        dwb = _ln_fold(dwb, C)
         return dx, dwb[0], dwb[1], None, None
 
 
@@ -1304,13 +1323,13 @@ class _LayerNormRes(torch.autograd.Function):
         if dres is not None:
             dres = _c(dres.to(x.dtype))
         dx = torch.empty_like(x)
-        dwb = torch.zeros(_LN_COPIES, 2, C, device=x.device, dtype=_f32)
+        dwb = _ln_accumulators(x.device, C)
         PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}{" +res" if dres is not None else ""}]',
                      (2 + (dres is not None)) * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
             hip.lib().ge_layernorm_bwd_multi(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
                                              hip.ptr(rstd), hip.ptr(dres), hip.ptr(dx), hip.ptr(dwb), _LN_COPIES, rows, C, hip.stream()),
             'ge_layernorm_bwd_multi'))
-        dwb = dwb.sum(0)
+        dwb = _ln_fold(dwb, C)
         return dx, dwb[0], dwb[1], None, None
 
 

@@ -153,6 +153,21 @@ def _sum_partials(part, weight, w_dtype):
     return part.sum(0, dtype=torch.float32).to(w_dtype)
 
 
+def _plain_dw(dy2, x2, weight, w_dtype):
+    """dW = dY^T X as ONE library GEMM (token counts too small for the split-K form).  bf16 operands with an fp32 master weight: the GEMM writes
+    its fp32 accumulators straight into the parameter's slice of the gradient arena (``torch.mm(..., out_dtype=float32, out=...)``) — no bf16
+    rounding of the result and no widening copy (Swin-L at 2 images per GPU: 96 copy launches per step)."""
+    if dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and w_dtype == torch.float32:
+        from .. import kernels
+        if 'mm_fp32_out' not in kernels.DISABLED:
+            from .optim import grad_target
+            out = grad_target(weight) if weight is not None else None
+            if out is not None and tuple(out.shape) == (dy2.shape[1], x2.shape[1]):
+                return torch.mm(dy2.t(), x2, out_dtype=torch.float32, out=out)
+            return torch.mm(dy2.t(), x2, out_dtype=torch.float32)
+    return _finished_grad(dy2.t() @ x2, weight, w_dtype)
+
+
 def _finished_grad(dw, weight, w_dtype):
     from .optim import grad_into_arena
     return grad_into_arena(weight, dw, w_dtype) if weight is not None else dw.to(w_dtype)
@@ -196,7 +211,7 @@ class _LinearTokens(torch.autograd.Function):
                     part = torch.bmm(dy2.view(splits, K // splits, M).transpose(1, 2), x2.view(splits, K // splits, N))
                     dw = _sum_partials(part, ctx.weight_ref, w_dtype)
                 else:
-                    dw = _finished_grad(dy2.t() @ x2, ctx.weight_ref, w_dtype)
+                    dw = _plain_dw(dy2, x2, ctx.weight_ref, w_dtype)
             if b_dtype is not None and ctx.needs_input_grad[2]:
                 if dy2.shape[1] % (4 if dy2.dtype == torch.float32 else 8) == 0:      # 16-byte channel vectors: one streaming pass
                     from .. import kernels
@@ -250,7 +265,7 @@ class _LinearBiasGelu(torch.autograd.Function):
                     part = torch.bmm(dy2.view(splits, K // splits, M).transpose(1, 2), x2.view(splits, K // splits, N))
                     dw = _sum_partials(part, ctx.weight_ref, w_dtype)
                 else:
-                    dw = _finished_grad(dy2.t() @ x2, ctx.weight_ref, w_dtype)
+                    dw = _plain_dw(dy2, x2, ctx.weight_ref, w_dtype)
         return dx, dw, (db.to(b_dtype) if ctx.needs_input_grad[2] else None), None
 
 

@@ -255,6 +255,9 @@ int ge_layernorm_bwd_res(const void* dy, int y_dtype, const void* x, int x_dtype
  * 1 <= copies <= 64. */
 int ge_layernorm_bwd_multi(const void* dy, int y_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                            const float* rstd, const void* dres, void* dx, float* dgb, int copies, long rows, int C, void* stream);
+/* The reduction of ge_layernorm_bwd_multi's accumulator copies that leaves them zero again: out (2, C) = sum over copies of dgb (copies, 2, C),
+ * dgb := 0 — a persistent accumulator buffer then needs no zero-fill per call (round 5, ABI 6). */
+int ge_layernorm_fold(float* dgb, float* out, int copies, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Residual connection with per-sample stochastic depth: out[b, :] = identity[b, :] + branch[b, :] * scale[b]
