@@ -14,7 +14,8 @@
 //     G = g^T X (ge_conv1x1_nhwc_wgrad, fp32) everything else is small-matrix algebra on G, the column sums and S (conv1x1_bn_bwd_finalize_k):
 //         d_beta = sum g,   d_gamma_c = rstd_c w_c . (G_c - sum g_c m)
 //         dW_c   = a_c (G_c - s m1_c - u_c m2_c)           u_c = rstd_c (S' w_c - s mean_c), S' = sum x x^T, s = sum x, m1 = d_beta / n, m2 = d_gamma / n
-//         dX     = g A1 + X A2 + c0       A1 = diag(a) W,  A2 = - W^T diag(rstd a m2) W,  c0 = ((mean rstd m2 - m1) a)^T W
+//         dX     = g A1 + X A2 + c0       A1 = diag(a) W,  A2 = - W^T diag(rstd a m2) W,  c0 = ((mean rstd m2 - m1) a)^T W   (conv1x1_bn_dgrad_k:
+//                                                 one pass over g and X with [A1; A2] resident in LDS)
 //     (the BatchNorm backward's mean-subtraction terms are rank-64 corrections of the two GEMMs the convolution backward runs anyway).
 // Statistics are those of the exact fp32 products (the two-pass path takes them from the bf16-rounded convolution output): bf16 mode only; the
 // fp32 parity mode keeps the two-pass kernels (csrc/nhwc.hip).
@@ -329,13 +330,13 @@ __global__ void __launch_bounds__(256) conv1x1_bn_mask_k(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward: the small-matrix algebra
-// one wave per output channel c (lane i = input channel): d_gamma, d_beta, dW[c][:], A1[c][:] = a_c w_c (bf16), and the per-channel
+// one wave per output channel c (lane i = input channel): d_gamma, d_beta, dW[c][:], column c of Wd = a_c w_c (bf16), and the per-channel
 // factors of the rank-64 corrections: k2[c] = rstd a m2, k0[c] = (mean rstd m2 - m1) a
 __global__ void __launch_bounds__(256) conv1x1_bn_bwd_finalize_k(const float* __restrict__ GT, const float* __restrict__ m1s, const double* __restrict__ gram,
                                                                  const bf16_t* __restrict__ w, const float* __restrict__ gamma,
                                                                  const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dW,
-                                                                 bf16_t* __restrict__ A1, float* __restrict__ k2, float* __restrict__ k0, int Cout, double n) {
+                                                                 bf16_t* __restrict__ Wd, float* __restrict__ k2, float* __restrict__ k0, int Cout, double n) {
   __shared__ double Ss[CB_K * 65];
   __shared__ double ss[CB_K];
   __shared__ double ws[4][CB_K];
@@ -356,7 +357,7 @@ __global__ void __launch_bounds__(256) conv1x1_bn_bwd_finalize_k(const float* __
   const double m1n = m1 / n, m2n = dg / n;
   const double ui = rstd * (t - si * mean);
   dW[(long)c * CB_K + lane] = (float)(a * (Gi - si * m1n - ui * m2n));
-  A1[(long)c * CB_K + lane] = f2bf((float)(a * wi));
+  Wd[(long)lane * (Cout + CB_K) + c] = f2bf((float)(a * wi));                   // A1^T: row = input channel, column = output channel
   if (lane == 0) {
     dgamma[c] = (float)dg;
     dbeta[c] = (float)m1;
@@ -364,9 +365,9 @@ __global__ void __launch_bounds__(256) conv1x1_bn_bwd_finalize_k(const float* __
     k0[c] = (float)((mean * rstd * m2n - m1n) * a);
   }
 }
-// A2[i][j] = - sum_c k2[c] w[c][i] w[c][j] (bf16, [64][64] row-major = the (K, N) operand of X A2);  c0[j] = sum_c k0[c] w[c][j]
+// Wd[j][Cout + i] = A2[i][j] = - sum_c k2[c] w[c][i] w[c][j] (symmetric);  c0[j] = sum_c k0[c] w[c][j]  (fp32)
 __global__ void __launch_bounds__(256) conv1x1_bn_bwd_a2_k(const bf16_t* __restrict__ w, const float* __restrict__ k2, const float* __restrict__ k0,
-                                                           bf16_t* __restrict__ A2, bf16_t* __restrict__ c0v, int Cout) {
+                                                           bf16_t* __restrict__ Wd, float* __restrict__ c0v, int Cout) {
   __shared__ float sm[4][CB_K];
   const int i = blockIdx.x, j = threadIdx.x & 63, sl = threadIdx.x >> 6;                 // four slices of the output channels per (i, j)
   float a = 0.f;
@@ -379,9 +380,85 @@ __global__ void __launch_bounds__(256) conv1x1_bn_bwd_a2_k(const bf16_t* __restr
   __syncthreads();
   if (sl == 0) {
     a = (sm[0][j] + sm[1][j]) + (sm[2][j] + sm[3][j]);
-    if (i < CB_K) A2[i * CB_K + j] = f2bf(a);
-    else c0v[j] = f2bf(a);
+    if (i < CB_K) Wd[(long)j * (Cout + CB_K) + Cout + i] = f2bf(a);
+    else c0v[j] = a;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: data gradient
+// dX (rows, 64) = [g | x] Wd^T + c0 with Wd (64, Cout + 64) resident in LDS (75 KB at Cout = 512): one streaming pass over g (the 0.8 GB operand)
+// and x.  Computed transposed, D[channel][token] = Wd-fragment x row-fragment: both fragments are 16 contiguous bytes (LDS / HBM), a lane ends
+// up with 4 consecutive channels of one token per accumulator group -> 8-byte stores.  Wave = 32 tokens; the rows are fetched eight K-steps
+// (8 x 16 B per lane) ahead of the MFMAs that use them, across tile boundaries.
+__global__ void __launch_bounds__(256) conv1x1_bn_dgrad_k(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x, const bf16_t* __restrict__ Wd,
+                                                          const float* __restrict__ c0, bf16_t* __restrict__ dx, long rows, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t wl[];                             // [64][Cout + 64 + 8]
+  const int KP = Cout + CB_K, LD = KP + 8, ppr = KP / 8;
+  for (int idx = threadIdx.x; idx < CB_K * ppr; idx += 256) {
+    const int r = idx / ppr, pc = idx - r * ppr;
+    *(uint4*)(wl + r * LD + pc * 8) = *(const uint4*)(Wd + (long)r * KP + pc * 8);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hi = lane >> 5, n = lane & 31;
+  float c0r[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0r[mt][r] = c0[mt * 32 + cb_row(r, hi)];
+  const bf16_t* wa = wl + n * LD + hi * 8;                                                // + mt * 32 * LD + k * 16
+  const long ntile = (rows + 31) / 32, tstep = (long)gridDim.x * 4;
+  const int nch = Cout / 128;                                                             // chunks of 8 K-steps over g
+  cb_bf16x8 Fa[8], Fb[8], Fx[4];
+#define CB_ROWPTR(T_) (((T_) * 32 + n < rows) ? (T_) * 32 + n : rows - 1)
+#define CB_LOADG(F_, T_, C_) { const bf16_t* gr_ = g + CB_ROWPTR(T_) * Cout + (C_) * 128 + hi * 8; _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) F_[s_] = *(const cb_bf16x8*)(gr_ + s_ * 16); }
+#define CB_MMA(F_, C_)                                                                                                         \
+  _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                                           \
+    const cb_bf16x8 w0_ = *(const cb_bf16x8*)(wa + ((C_) * 8 + s_) * 16), w1_ = *(const cb_bf16x8*)(wa + 32 * LD + ((C_) * 8 + s_) * 16); \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0_, F_[s_], acc0, 0, 0, 0);                                                 \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1_, F_[s_], acc1, 0, 0, 0);                                                 \
+  }
+  long tile = (long)blockIdx.x * 4 + wv;
+  if (tile < ntile) CB_LOADG(Fa, tile, 0)
+  for (; tile < ntile; tile += tstep) {
+    {
+      const bf16_t* xr = x + CB_ROWPTR(tile) * CB_K + hi * 8;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) Fx[s] = *(const cb_bf16x8*)(xr + s * 16);
+    }
+    cb_f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int c = 0; c < nch; c += 2) {
+      if (c + 1 < nch) CB_LOADG(Fb, tile, c + 1)
+      CB_MMA(Fa, c)
+      if (c + 2 < nch) CB_LOADG(Fa, tile, c + 2)
+      else if (tile + tstep < ntile) CB_LOADG(Fa, tile + tstep, 0)
+      if (c + 1 < nch) CB_MMA(Fb, c + 1)
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const cb_bf16x8 w0 = *(const cb_bf16x8*)(wa + Cout + s * 16), w1 = *(const cb_bf16x8*)(wa + 32 * LD + Cout + s * 16);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, Fx[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, Fx[s], acc1, 0, 0, 0);
+    }
+    const long row = tile * 32 + n;
+    if (row < rows) {
+      bf16_t* o = dx + row * CB_K + 4 * hi;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        uint2 v0, v1;
+        v0.x = (uint32_t)f2bf(acc0[4 * r4] + c0r[0][4 * r4]) | ((uint32_t)f2bf(acc0[4 * r4 + 1] + c0r[0][4 * r4 + 1]) << 16);
+        v0.y = (uint32_t)f2bf(acc0[4 * r4 + 2] + c0r[0][4 * r4 + 2]) | ((uint32_t)f2bf(acc0[4 * r4 + 3] + c0r[0][4 * r4 + 3]) << 16);
+        v1.x = (uint32_t)f2bf(acc1[4 * r4] + c0r[1][4 * r4]) | ((uint32_t)f2bf(acc1[4 * r4 + 1] + c0r[1][4 * r4 + 1]) << 16);
+        v1.y = (uint32_t)f2bf(acc1[4 * r4 + 2] + c0r[1][4 * r4 + 2]) | ((uint32_t)f2bf(acc1[4 * r4 + 3] + c0r[1][4 * r4 + 3]) << 16);
+        *(uint2*)(o + 8 * r4) = v0;
+        *(uint2*)(o + 32 + 8 * r4) = v1;
+      }
+    }
+  }
+#undef CB_ROWPTR
+#undef CB_LOADG
+#undef CB_MMA
 }
 
 // ================================================================================================ C ABI
@@ -462,17 +539,38 @@ extern "C" int ge_conv1x1_bn_bwd_mask(const void* dy1, long ld1, const void* dy2
 }
 
 // The algebra after G = g^T X (GT: (Cout, 64) fp32, ge_conv1x1_nhwc_wgrad) and colsum: d_gamma, d_beta, dW (Cout, 64) fp32, and the operands of
-// dX = g A1 + X A2 + c0: A1 (Cout, 64) bf16, A2 (64, 64) bf16, c0 (64) bf16.  scratch: 2 Cout floats.
+// dX = [g | x] Wd^T + c0 (ge_conv1x1_bn_dgrad): Wd (64, Cout + 64) bf16, c0 (64) fp32.  scratch: 2 Cout floats.
 extern "C" int ge_conv1x1_bn_bwd_finalize(const float* GT, const float* colsum, const double* gram, const void* w, const float* gamma,
                                           const float* save_mean, const float* save_rstd, long rows, int Cin, int Cout, float* dgamma, float* dbeta,
-                                          float* dW, void* A1, void* A2, void* c0, float* scratch, void* stream) {
-  if (!GT || !colsum || !gram || !w || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !dW || !A1 || !A2 || !c0 || !scratch || rows <= 0) return GE_ERR_BAD_ARG;
+                                          float* dW, void* Wd, float* c0, float* scratch, void* stream) {
+  if (!GT || !colsum || !gram || !w || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !dW || !Wd || !c0 || !scratch || rows <= 0) return GE_ERR_BAD_ARG;
   if (!cb_ok(Cin, Cout)) return GE_ERR_UNSUPPORTED;
   hipStream_t s = ge_stream(stream);
-  conv1x1_bn_bwd_finalize_k<<<(Cout + 3) / 4, 256, 0, s>>>(GT, colsum, gram, (const bf16_t*)w, gamma, save_mean, save_rstd, dgamma, dbeta, dW, (bf16_t*)A1,
+  conv1x1_bn_bwd_finalize_k<<<(Cout + 3) / 4, 256, 0, s>>>(GT, colsum, gram, (const bf16_t*)w, gamma, save_mean, save_rstd, dgamma, dbeta, dW, (bf16_t*)Wd,
                                                            scratch, scratch + Cout, Cout, (double)rows);
   GE_LAUNCH_CHECK();
-  conv1x1_bn_bwd_a2_k<<<CB_K + 1, 256, 0, s>>>((const bf16_t*)w, scratch, scratch + Cout, (bf16_t*)A2, (bf16_t*)c0, Cout);
+  conv1x1_bn_bwd_a2_k<<<CB_K + 1, 256, 0, s>>>((const bf16_t*)w, scratch, scratch + Cout, (bf16_t*)Wd, c0, Cout);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+// dx (rows, 64) bf16 = g (rows, Cout) Wd[:, :Cout]^T + x (rows, 64) Wd[:, Cout:]^T + c0: the convolution's data gradient with the BatchNorm scale
+// folded into the weights plus the rank-64 mean-subtraction terms, one pass.  Cout <= 1024 (Wd lives in LDS).
+extern "C" int ge_conv1x1_bn_dgrad(const void* g, const void* x, const void* Wd, const float* c0, void* dx, long rows, int Cin, int Cout, void* stream) {
+  if (!g || !x || !Wd || !c0 || !dx || rows <= 0) return GE_ERR_BAD_ARG;
+  if (!cb_ok(Cin, Cout) || Cout > 1024 || (((uintptr_t)g | (uintptr_t)x | (uintptr_t)Wd | (uintptr_t)dx) & 15)) return GE_ERR_UNSUPPORTED;
+  const int cus = ge_cu_count();
+  if (!cus) return GE_ERR_BAD_ARG;
+  const size_t smem = (size_t)CB_K * (Cout + CB_K + 8) * sizeof(bf16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv1x1_bn_dgrad_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GE_ERR_UNSUPPORTED;
+    attr_set = true;
+  }
+  const long ntile = (rows + 31) / 32;
+  long wgs = (long)cus * (smem <= 78 * 1024 ? 2 : 1);
+  if (wgs > (ntile + 3) / 4) wgs = (ntile + 3) / 4;
+  conv1x1_bn_dgrad_k<<<(unsigned)wgs, 256, smem, ge_stream(stream)>>>((const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)Wd, c0, (bf16_t*)dx, rows, Cout);
   GE_LAUNCH_CHECK();
   return GE_OK;
 }

@@ -93,7 +93,8 @@ SIGNATURES = {
     'ge_conv1x1_bn_stats': (_i, [_vp, _l, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ge_conv1x1_bn_act_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _i, _f, _vp]),
     'ge_conv1x1_bn_bwd_mask': (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
-    'ge_conv1x1_bn_bwd_finalize': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ge_conv1x1_bn_bwd_finalize': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ge_conv1x1_bn_dgrad': (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     'ge_conv3x3_c1_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_conv3x3_c1_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ge_gemm_nt': (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _l, _i, _i, _i, _vp]),

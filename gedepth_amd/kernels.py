@@ -1591,17 +1591,18 @@ class _Conv1x1BNActPos(torch.autograd.Function):
             lib.ge_conv1x1_nhwc_wgrad(_raw_ptr(x, 'x'), hip.ptr(g), hip.ptr(GT), rows, Cin, Cout, hip.GE_BF16, hip.stream()), 'ge_conv1x1_nhwc_wgrad'))
         small = torch.empty(2 * Cout + Cout * Cin + 2 * Cout, device=dev, dtype=_f32)
         dgamma, dbeta, dW, scratch = small[:Cout], small[Cout:2 * Cout], small[2 * Cout:2 * Cout + Cout * Cin].view(Cout, Cin), small[2 * Cout + Cout * Cin:]
-        ops = torch.empty(Cout * Cin + Cin * Cin + Cin, device=dev, dtype=x.dtype)
-        A1, A2, c0 = ops[:Cout * Cin].view(Cout, Cin), ops[Cout * Cin:Cout * Cin + Cin * Cin].view(Cin, Cin), ops[Cout * Cin + Cin * Cin:]
+        Wd = torch.empty(Cin, Cout + Cin, device=dev, dtype=x.dtype)
+        c0 = torch.empty(Cin, device=dev, dtype=_f32)
         hip.check(lib.ge_conv1x1_bn_bwd_finalize(hip.ptr(GT), hip.ptr(m1), hip.ptr(gram), hip.ptr(wc), hip.ptr(g32), hip.ptr(stats[0]), hip.ptr(stats[1]),
-                                                 rows, Cin, Cout, hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dW), hip.ptr(A1), hip.ptr(A2), hip.ptr(c0),
+                                                 rows, Cin, Cout, hip.ptr(dgamma), hip.ptr(dbeta), hip.ptr(dW), hip.ptr(Wd), hip.ptr(c0),
                                                  hip.ptr(scratch), hip.stream()), 'ge_conv1x1_bn_bwd_finalize')
         dx = None
         if ctx.needs_input_grad[0]:
-            x2 = x.permute(0, 2, 3, 1).reshape(rows, Cin)
-            dx2 = torch.addmm(c0, x2, A2)                      # the rank-64 corrections of the BatchNorm backward ...
-            dx2.addmm_(g, A1)                                  # ... + the convolution's data gradient with the scale folded into the weights
-            dx = dx2.view(B, H, W, Cin).permute(0, 3, 1, 2)
+            # the convolution's data gradient with the BatchNorm scale folded into the weights + the rank-64 corrections of the BatchNorm backward
+            dx = torch.empty_like(x)
+            PROFILER.run(f'conv1x1_bn_dgrad[{B}x{Cout}->{Cin} {H}x{W}]', (g.numel() + 2 * x.numel()) * 2, lambda: hip.check(
+                lib.ge_conv1x1_bn_dgrad(hip.ptr(g), _raw_ptr(x, 'x'), hip.ptr(Wd), hip.ptr(c0), _raw_ptr(dx, 'dx'), rows, Cin, Cout, hip.stream()),
+                'ge_conv1x1_bn_dgrad'))
         dw = dW.view(Cout, Cin, 1, 1)
         if ctx.weight_ref is not None:
             from .mmrt.optim import grad_into_arena
@@ -1618,7 +1619,7 @@ def conv1x1_bn_act_pos_ok(block, x):
     conv, bn = block.conv, block.norm
     return ('conv1x1_bn' not in DISABLED and x.is_cuda and x.dtype == torch.bfloat16 and type(conv) is torch.nn.Conv2d and conv.kernel_size == (1, 1)
             and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.in_channels == 64
-            and conv.out_channels % 128 == 0 and conv.out_channels <= 2048 and conv.weight.dtype == _f32
+            and conv.out_channels % 128 == 0 and conv.out_channels <= 1024 and conv.weight.dtype == _f32
             and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
             and block._fused_bn_slope() is not None and _is_cl(x) and x.data_ptr() % 16 == 0)
 

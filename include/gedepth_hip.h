@@ -454,7 +454,8 @@ int ge_conv1x1_nhwc_wgrad(const void* x, const void* dy, float* dw, long M, int 
  *   ge_conv1x1_bn_bwd_mask   g (rows, C) bf16 = (dy1 + dy2) * act'(y) and its column sums; dy1 / dy2 bf16 with row strides ld1 / ld2 (elements),
  *                            either may be NULL — a gradient that arrives as a channel slice of a wider map is read in place.
  *   ge_conv1x1_bn_bwd_finalize  from GT = g^T x ((Cout, 64) fp32: ge_conv1x1_nhwc_wgrad), the column sums and gram: d_gamma, d_beta, dW (Cout, 64)
- *                            fp32, and the operands of dX = g A1 + x A2 + c0 (A1 (Cout, 64), A2 (64, 64), c0 (64), all bf16); scratch 2 Cout floats. */
+ *                            fp32, and the operands of the data gradient: Wd (64, Cout + 64) bf16, c0 (64) fp32; scratch 2 Cout floats.
+ *   ge_conv1x1_bn_dgrad      dx (rows, 64) bf16 = [g | x] Wd^T + c0 in one pass over g and x (Wd resident in LDS; Cout <= 1024). */
 size_t ge_conv1x1_bn_workspace(int Cin, int Cout);
 int ge_conv1x1_bn_stats(const void* x, long rows, int Cin, const void* w, int Cout, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float eps, float momentum, double* gram, float* save_mean, float* save_rstd, float* coef,
@@ -464,8 +465,9 @@ int ge_conv1x1_bn_act_fwd(const void* x, const void* w, const float* coef, const
 int ge_conv1x1_bn_bwd_mask(const void* dy1, long ld1, const void* dy2, long ld2, const void* y, void* g, float* colsum, void* workspace, long rows,
                            int C, float slope, void* stream);
 int ge_conv1x1_bn_bwd_finalize(const float* GT, const float* colsum, const double* gram, const void* w, const float* gamma, const float* save_mean,
-                               const float* save_rstd, long rows, int Cin, int Cout, float* dgamma, float* dbeta, float* dW, void* A1, void* A2,
-                               void* c0, float* scratch, void* stream);
+                               const float* save_rstd, long rows, int Cin, int Cout, float* dgamma, float* dbeta, float* dW, void* Wd, float* c0,
+                               float* scratch, void* stream);
+int ge_conv1x1_bn_dgrad(const void* g, const void* x, const void* Wd, const float* c0, void* dx, long rows, int Cin, int Cout, void* stream);
 /* The same layer with ONE output channel (csrc/conv3x3_c1.hip): the depth regressor `conv_depth` (reference
  * depth/models/decode_heads/decode_head.py: nn.Conv2d(channels, 1, 3, padding=1)) and `convfinal` of the ground-attention neck
  * (necks/pemask_neck.py:36-42): a streaming reduction on the vector pipe (v_dot2c_f32_bf16), not a GEMM with N = 1.
