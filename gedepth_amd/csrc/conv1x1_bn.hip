@@ -169,6 +169,12 @@ __global__ void __launch_bounds__(256) conv1x1_bn_finalize_k(const double* __res
 #ifndef CB_EPI_GROUP
 #define CB_EPI_GROUP 4
 #endif
+typedef unsigned cb_u32x4 __attribute__((ext_vector_type(4)));
+#ifdef CB_NT_STORE
+#define CB_STORE16(P_, V_) { const uint4 v__ = (V_); __builtin_nontemporal_store((cb_u32x4){v__.x, v__.y, v__.z, v__.w}, (cb_u32x4*)(P_)); }
+#else
+#define CB_STORE16(P_, V_) *(uint4*)(P_) = (V_)
+#endif
 #define CB_YLD 136                      // LDS row stride (bf16) of the wave's [32 tokens][128 channels] output tile
 template <bool HAS_POS>
 __global__ void __launch_bounds__(256) conv1x1_bn_act_k(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ coef,
@@ -246,7 +252,7 @@ __global__ void __launch_bounds__(256) conv1x1_bn_act_k(const bf16_t* __restrict
       for (int i = 0; i < CB_EPI_GROUP; ++i) {
         const int idx = (i0 + i) * 64 + lane, tok = idx >> 4, piece = idx & 15;
         v[i] = *(const uint4*)(ytile + tok * CB_YLD + piece * 8);
-        if (p0 + tok < HW) *(uint4*)(y + ((long)b * HW + p0 + tok) * Cout + c0 + piece * 8) = v[i];
+        if (p0 + tok < HW) CB_STORE16(y + ((long)b * HW + p0 + tok) * Cout + c0 + piece * 8, v[i]);
       }
       if (HAS_POS) {
 #pragma unroll
@@ -260,7 +266,7 @@ __global__ void __launch_bounds__(256) conv1x1_bn_act_k(const bf16_t* __restrict
             const float lo = __uint_as_float(u[k] << 16) + e[2 * k], hi2 = __uint_as_float(u[k] & 0xffff0000u) + e[2 * k + 1];
             o[k] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi2) << 16);
           }
-          if (p0 + tok < HW) *(uint4*)(q + ((long)b * HW + p0 + tok) * Cout + c0 + piece * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+          if (p0 + tok < HW) CB_STORE16(q + ((long)b * HW + p0 + tok) * Cout + c0 + piece * 8, make_uint4(o[0], o[1], o[2], o[3]));
         }
       }
     }
