@@ -293,6 +293,11 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         respawn_under_launcher(args)
+    # stdout carries ONE JSON line: RCCL prints its version banner there when the first communicator is created, MIOpen / hipBLASLt may
+    # print too — everything written to descriptor 1 from here on goes to stderr, the result line to the saved descriptor
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     from gedepth_amd.mmrt.ddp import init_dist
     rank, local, world = init_dist('nccl')
     assert torch.cuda.is_available(), 'bench.py measures the MI355X path; there is no CPU fallback'
@@ -427,7 +432,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             note('cpu baseline (oracle, 1+3 train steps, 1+3 eval)')
             res['cpu_baseline'] = cpu_baseline(args.config, args.height, args.width)
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=result_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

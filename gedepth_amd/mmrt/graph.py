@@ -18,6 +18,8 @@ What makes the step capturable (all of it lives elsewhere, this file only orches
 Host-side heuristics evaluated at capture time are frozen into the graph (the cross-attention's query order, the d_value kernel
 choice): results do not depend on them, and ``recapture()`` refreshes them.
 """
+import os
+
 import torch
 
 from .. import hip
@@ -37,6 +39,13 @@ class GraphedTrainStep:
         self.salt = torch.zeros(1, device=dev, dtype=torch.int64)       # dropout counter, advanced inside the graph
         self._warmup_left = int(warmup)
         self.disabled = False                    # set when a capture failed: the object then runs every step eagerly
+        # RCCL collectives inside the captured step: captured and replayed correctly at world size 1 (forced exchange) in two of three
+        # sessions; in the third the process group's watchdog thread queried an event recorded in the capturing stream
+        # (hipErrorCapturedEvent) and aborted the process — not catchable from here.  Until the exchange is taken out of the watchdog's
+        # view, a step with an ACTIVE gradient exchange is captured only on request (GE_GRAPH_DDP=1) and otherwise runs eagerly.
+        if ddp is not None and getattr(ddp, 'active', False) and os.environ.get('GE_GRAPH_DDP') != '1':
+            self.disabled = True
+            self.disabled_reason = 'gradient exchange active: capture is opt-in (GE_GRAPH_DDP=1)'
         self.stream = torch.cuda.Stream(dev)                             # warm-up steps and the capture share this side stream
 
     # ---- one step, eager or being captured
