@@ -39,13 +39,10 @@ class GraphedTrainStep:
         self.salt = torch.zeros(1, device=dev, dtype=torch.int64)       # dropout counter, advanced inside the graph
         self._warmup_left = int(warmup)
         self.disabled = False                    # set when a capture failed: the object then runs every step eagerly
-        # RCCL collectives inside the captured step: captured and replayed correctly at world size 1 (forced exchange) in two of three
-        # sessions; in the third the process group's watchdog thread queried an event recorded in the capturing stream
-        # (hipErrorCapturedEvent) and aborted the process — not catchable from here.  Until the exchange is taken out of the watchdog's
-        # view, a step with an ACTIVE gradient exchange is captured only on request (GE_GRAPH_DDP=1) and otherwise runs eagerly.
-        if ddp is not None and getattr(ddp, 'active', False) and os.environ.get('GE_GRAPH_DDP') != '1':
+        # RCCL collectives inside the captured step (FlatDDP's bucket all-reduces, the stacked loss all-reduce): see capture() for the one
+        # precaution they need.  GE_GRAPH_DDP=0 keeps a step with an active gradient exchange eager.
+        if ddp is not None and getattr(ddp, 'active', False) and os.environ.get('GE_GRAPH_DDP') == '0':
             self.disabled = True
-            self.disabled_reason = 'gradient exchange active: capture is opt-in (GE_GRAPH_DDP=1)'
         self.stream = torch.cuda.Stream(dev)                             # warm-up steps and the capture share this side stream
 
     # ---- one step, eager or being captured
@@ -77,6 +74,13 @@ class GraphedTrainStep:
         dev = self.optimizer.arena.flat_param.device
         lib = hip.lib()
         torch.cuda.synchronize(dev)
+        if self.ddp is not None and getattr(self.ddp, 'active', False):
+            # The process group's watchdog thread polls the end events of the collectives of the last EAGER step (every 100 ms) until it has
+            # seen them complete.  Once the RCCL stream has joined the capture, hipEventQuery on such an event fails with
+            # hipErrorCapturedEvent and the watchdog aborts the process (2 - 3 of 5 sessions when the capture followed the last eager step
+            # directly; 0 of 8 with this pause, tools/final_round_run.sh's forced-exchange runs): let it retire them first.
+            import time
+            time.sleep(float(os.environ.get('GE_GRAPH_DDP_SETTLE', '0.5')))
         g = torch.cuda.CUDAGraph()
         hip.check(lib.ge_rng_salt(self.salt.data_ptr()), 'ge_rng_salt')
         try:
