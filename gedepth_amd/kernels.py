@@ -1081,11 +1081,78 @@ def conv1x1_wgrad(x, dy):
     return dw
 
 
+# rows (N H W) up to which a 1x1 convolution runs as token GEMMs: measured same-session on MI355X — every 1x1 layer through the GEMM path costs the
+# 8-image step +0.3 ms (MIOpen's tuned implicit-GEMM kernels win on the 2e5 - 8e5-row maps) and saves the 2-image Swin-L step 0.33 ms (on maps
+# of 770 - 49 280 rows MIOpen spends 50 - 110 us per layer backward for 10 - 30 us of work)
+_CONV1X1_GEMM_ROWS = int(os.environ.get('GE_CONV1X1_GEMM_ROWS', '65536'))
+
+
+class _Conv1x1Gemm(torch.autograd.Function):
+    """A bias-free 1x1 / stride-1 convolution of a channels-last bf16 map as the token GEMM it is (rows = N H W): forward and data gradient
+    through the token-Linear path of mmrt.bricks (tuned hipBLASLt solution or ge_gemm_nt), weight gradient split-K / plain with fp32
+    accumulators written into the gradient arena — instead of MIOpen's implicit-GEMM kernels, their zero-fill launches and the widening copy of
+    their bf16 weight gradient (the lateral / trans_proj blocks of the HAHI neck, reference necks/hahi.py:120-137)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        from .mmrt import bricks
+        from .mmrt.optim import lowp
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        wc = lowp(weight, torch.bfloat16).detach().reshape(Cout, Cin)
+        x2 = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+        with torch.autocast('cuda', enabled=False):
+            y2 = bricks._linear_fwd(x2, wc, None, None, torch.bfloat16)
+        ctx.save_for_backward(x, wc)
+        ctx.w_dtype = weight.dtype
+        ctx.weight_ref = weight if isinstance(weight, torch.nn.Parameter) else None
+        return y2.view(B, H, W, Cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .mmrt import bricks
+        from .mmrt.optim import grad_target
+        x, wc = ctx.saved_tensors
+        B, Cin, H, W = x.shape
+        Cout = wc.shape[0]
+        rows = B * H * W
+        dy2 = _cl(dy.to(torch.bfloat16)).permute(0, 2, 3, 1).reshape(rows, Cout)
+        x2 = x.permute(0, 2, 3, 1).reshape(rows, Cin)
+        dx = dw = None
+        with torch.autocast('cuda', enabled=False):
+            if ctx.needs_input_grad[0]:
+                dx = bricks._linear_dx(dy2, wc).view(B, H, W, Cin).permute(0, 3, 1, 2)
+            if ctx.needs_input_grad[1]:
+                # two aliases of the parameter's arena slice: the (Cout, Cin) one the GEMM writes, the parameter-shaped one autograd adopts
+                tgt = grad_target(ctx.weight_ref) if (ctx.weight_ref is not None and ctx.w_dtype == _f32) else None
+                out2 = grad_target(ctx.weight_ref).view(Cout, Cin) if tgt is not None else None
+                splits = bricks._split_k(rows)
+                if splits:
+                    part = torch.bmm(dy2.view(splits, rows // splits, Cout).transpose(1, 2), x2.view(splits, rows // splits, Cin))
+                    dw2 = torch.sum(part, 0, dtype=_f32, out=out2) if out2 is not None else part.sum(0, dtype=_f32)
+                else:
+                    dw2 = torch.mm(dy2.t(), x2, out_dtype=_f32, out=out2) if out2 is not None else torch.mm(dy2.t(), x2, out_dtype=_f32)
+                dw = tgt if tgt is not None else dw2.view(Cout, Cin, 1, 1).to(ctx.w_dtype)
+                del out2
+        return dx, dw
+
+
+def conv1x1_gemm_ok(conv, x):
+    """A ConvModule's bias-free 1x1 convolution can run as a token GEMM (``_Conv1x1Gemm``): bf16 autocast training, channels-last bf16 input,
+    plain 1x1 geometry, channel counts that are whole 16-byte vectors.  ``GE_DISABLE=conv1x1_gemm`` keeps MIOpen."""
+    return ('conv1x1_gemm' not in DISABLED and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and x.dtype == torch.bfloat16 and _is_cl(x) and conv.in_channels % 8 == 0
+            and conv.out_channels % 8 == 0 and x.data_ptr() % 16 == 0
+            and x.shape[0] * x.shape[2] * x.shape[3] <= _CONV1X1_GEMM_ROWS)
+
+
 def conv_lib(conv, x):
     """``conv._conv_forward(x, conv.weight, None)`` (no bias) — through ``_ConvLib`` when bf16 autocast training applies, else unchanged."""
     if (x.is_cuda and type(conv) is torch.nn.Conv2d and conv.padding_mode == 'zeros' and torch.is_grad_enabled() and conv.weight.requires_grad
             and torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16 and conv.weight.dtype == _f32
             and not isinstance(conv.padding, str) and 'conv_lib' not in DISABLED):
+        if conv1x1_gemm_ok(conv, x):
+            return _Conv1x1Gemm.apply(x, conv.weight)
         return _ConvLib.apply(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
     return conv._conv_forward(x, conv.weight, None)
 

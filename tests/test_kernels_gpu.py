@@ -1216,6 +1216,32 @@ def test_conv1x1_bn_act_pos_vs_fp32_composition(dev, shape, cout, mode):
     assert errs['dx'] <= 1e-2 and errs['dw'] <= 6e-3 and errs['dgamma'] <= 6e-3 and errs['dbeta'] <= 6e-3, errs
 
 
+@pytest.mark.parametrize('shape,cout', [((2, 96, 24, 40), 512), ((8, 768, 11, 35), 768), ((2, 64, 88, 140), 64)])            # the last: 24 640 rows, split-K weight gradient
+def test_conv1x1_as_token_gemm_vs_fp32_conv(dev, shape, cout):
+    """kernels._Conv1x1Gemm: a bias-free 1x1 convolution of a channels-last bf16 map as a token GEMM (forward, data gradient, split-K or plain
+    weight gradient in fp32) against F.conv2d in fp32 on the same bf16 inputs and bf16-rounded weight."""
+    from gedepth_amd import kernels as K
+    g = gen(91)
+    B, Cin, H, W = shape
+    conv = torch.nn.Conv2d(Cin, cout, 1, bias=False)
+    x = torch.randn(*shape, generator=g).to(torch.bfloat16)
+    gy = torch.randn(B, cout, H, W, generator=g).to(torch.bfloat16)
+    xr = x.float().clone().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    yr.backward(gy.float())
+    conv = conv.to(dev)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert K.conv1x1_gemm_ok(conv, xg)
+        y = K.conv_lib(conv, xg)
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last) and tuple(y.shape) == (B, cout, H, W)
+    y.backward(gy.to(dev).contiguous(memory_format=torch.channels_last))
+    errs = dict(y=l2rel(y.float(), yr), dx=l2rel(xg.grad.float(), xr.grad), dw=l2rel(conv.weight.grad, wr.grad))
+    print(f'\n[conv1x1 as GEMM {shape}->{cout}]', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert errs['y'] <= 4e-3 and errs['dx'] <= 4e-3 and errs['dw'] <= 4e-3, errs          # bf16 storage of y / dx; dW: bf16 split-K partials
+
+
 @pytest.mark.gpu
 def test_conv_module_bn_relu_fused_matches_unfused(dev):
     from gedepth_amd.mmrt.bricks import ConvModule
