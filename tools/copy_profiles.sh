@@ -4,11 +4,12 @@ SRC=${1:-r5}; DST=${2:-$SRC}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final_$SRC; P=gpurun_out/prof_$SRC
 cp $F/bench.json profiles/${DST}_bench.json
-for n in config3 config3_eager config4 config5 ddp_forced ddp_forced_config3; do cp $F/bench_$n.json profiles/${DST}_bench_$n.json; done
+for n in config3 config3_eager config4 config5 ddp_forced ddp_forced_config3 ddp_forced_config3_eager; do cp $F/bench_$n.json profiles/${DST}_bench_$n.json; done
 cp $F/config3_busy.txt profiles/${DST}_config3_graph_busy.txt
 cp $F/dv_time.txt profiles/${DST}_dv_time.txt
 cp $F/library_roofline.txt profiles/${DST}_library_roofline.txt
 cp $F/aten_call_sites.txt profiles/${DST}_aten_call_sites.txt
+cp $F/aten_call_sites_config3.txt profiles/${DST}_aten_call_sites_config3.txt
 cp $F/parity_e2e.json profiles/${DST}_parity_e2e.json
 cp $P/kernel_stats.csv profiles/${DST}_bench_kernel_stats.csv
 cp $P/domain_stats.csv profiles/${DST}_bench_domain_stats.csv

@@ -16,8 +16,10 @@ python bench.py --attn fp8 --no-cpu-baseline --no-fp32 > $OUT/bench_config5.json
 # gradient exchange forced on one rank: bucket layout in arrival order + per-bucket launch / completion trace
 GE_DDP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-fp32 --no-h2d --no-kernel-timing > $OUT/bench_ddp_forced.json 2> /dev/null
 GE_DDP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --config depthformer_a.py --no-cpu-baseline --no-fp32 --no-h2d --no-kernel-timing > $OUT/bench_ddp_forced_config3.json 2> /dev/null
+GE_GRAPH_DDP=0 GE_DDP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --config depthformer_a.py --no-cpu-baseline --no-fp32 --no-h2d --no-kernel-timing > $OUT/bench_ddp_forced_config3_eager.json 2> /dev/null
 python tools/library_roofline.py > $OUT/library_roofline.txt 2>&1
 python tools/ubench/aten_sites.py > $OUT/aten_call_sites.txt 2>&1
+CFG=depthformer_a.py python tools/ubench/aten_sites.py > $OUT/aten_call_sites_config3.txt 2>&1
 for g in model concentrated spread; do python tools/ubench/msda_mm/dv_time.py $g 2>&1 | grep -v amdgpu.ids; done > $OUT/dv_time.txt
 # config 3: GPU idle share with and without the hipGraph (kernel trace of the last 10 steps)
 ( cd /tmp && export TMPDIR=/tmp; A="--no-cpu-baseline --no-fp32 --no-kernel-timing --no-h2d --config depthformer_a.py --steps 20 --warmup 5"
