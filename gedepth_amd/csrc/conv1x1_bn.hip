@@ -31,6 +31,12 @@ typedef float cb_f32x16 __attribute__((ext_vector_type(16)));
 #define CB_GRAM (65 * CB_K)             // 64 x 64 sums of products + 64 column sums
 #define CB_GRAM_WG 256                  // partial Gram matrices (one per workgroup)
 
+// fp32 -> bf16 on the conversion unit (v_cvt_pk_bf16_f32, round to nearest even): the software rounding of common.h costs ~6 VALU per value,
+// a third of this file's forward kernel
+typedef __bf16 cb_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t cb_bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t cb_pk(float lo, float hi) { return __builtin_bit_cast(uint32_t, (cb_bf16x2){(__bf16)lo, (__bf16)hi}); }
+
 __device__ __forceinline__ int cb_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }      // C/D layout of v_mfma_f32_32x32x16: row of register r
 
 // ------------------------------------------------------------------------------------------------ input moments
@@ -229,7 +235,7 @@ __global__ void __launch_bounds__(256) conv1x1_bn_act_k(const bf16_t* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float z = __fmaf_rn(acc[jb][r], ca[jb], cbv[jb]);
-        ytile[cb_row(r, hi) * CB_YLD + jb * 32 + n] = f2bf(z > 0.f ? z : z * slope);
+        ytile[cb_row(r, hi) * CB_YLD + jb * 32 + n] = cb_bf(z > 0.f ? z : z * slope);
       }
     __builtin_amdgcn_wave_barrier();
     // rows back out of LDS as 16-byte pieces (16 lanes = one token's 256 bytes); CB_EPI_GROUP pieces per lane are handled together so that
@@ -264,7 +270,7 @@ __global__ void __launch_bounds__(256) conv1x1_bn_act_k(const bf16_t* __restrict
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float lo = __uint_as_float(u[k] << 16) + e[2 * k], hi2 = __uint_as_float(u[k] & 0xffff0000u) + e[2 * k + 1];
-            o[k] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi2) << 16);
+            o[k] = cb_pk(lo, hi2);
           }
           if (p0 + tok < HW) CB_STORE16(q + ((long)b * HW + p0 + tok) * Cout + c0 + piece * 8, make_uint4(o[0], o[1], o[2], o[3]));
         }
@@ -453,10 +459,10 @@ __global__ void __launch_bounds__(256) conv1x1_bn_dgrad_k(const bf16_t* __restri
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         uint2 v0, v1;
-        v0.x = (uint32_t)f2bf(acc0[4 * r4] + c0r[0][4 * r4]) | ((uint32_t)f2bf(acc0[4 * r4 + 1] + c0r[0][4 * r4 + 1]) << 16);
-        v0.y = (uint32_t)f2bf(acc0[4 * r4 + 2] + c0r[0][4 * r4 + 2]) | ((uint32_t)f2bf(acc0[4 * r4 + 3] + c0r[0][4 * r4 + 3]) << 16);
-        v1.x = (uint32_t)f2bf(acc1[4 * r4] + c0r[1][4 * r4]) | ((uint32_t)f2bf(acc1[4 * r4 + 1] + c0r[1][4 * r4 + 1]) << 16);
-        v1.y = (uint32_t)f2bf(acc1[4 * r4 + 2] + c0r[1][4 * r4 + 2]) | ((uint32_t)f2bf(acc1[4 * r4 + 3] + c0r[1][4 * r4 + 3]) << 16);
+        v0.x = cb_pk(acc0[4 * r4] + c0r[0][4 * r4], acc0[4 * r4 + 1] + c0r[0][4 * r4 + 1]);
+        v0.y = cb_pk(acc0[4 * r4 + 2] + c0r[0][4 * r4 + 2], acc0[4 * r4 + 3] + c0r[0][4 * r4 + 3]);
+        v1.x = cb_pk(acc1[4 * r4] + c0r[1][4 * r4], acc1[4 * r4 + 1] + c0r[1][4 * r4 + 1]);
+        v1.y = cb_pk(acc1[4 * r4 + 2] + c0r[1][4 * r4 + 2], acc1[4 * r4 + 3] + c0r[1][4 * r4 + 3]);
         *(uint2*)(o + 8 * r4) = v0;
         *(uint2*)(o + 32 + 8 * r4) = v1;
       }

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libgedepth_hip.so')
+LIB_PATH = os.environ.get('GE_LIB') or os.path.join(_HERE, 'csrc', 'libgedepth_hip.so')     # GE_LIB: a differently built library (A/B timing)
 GE_F32, GE_BF16 = 0, 1
 
 _c = ctypes
