@@ -100,6 +100,26 @@ const unsigned long long* ge_rng_salt_get();
 __device__ __forceinline__ uint64_t ge_salted(uint64_t seed, const unsigned long long* salt) {
   return salt ? seed + (uint64_t)*salt * 0x9E3779B97F4A7C15ull : seed;
 }
+// Dropout keep decisions: ONE 64-bit hash (splitmix64 finaliser) per group of four consecutive element indices, 16 bits per element:
+// element idx is kept when bits [16 (idx & 3), +16) of hash(seed, idx >> 2) are >= thr = round(p * 65536) (keep probability 1 - thr / 65536: p = 0.1 ->
+// 0.899994).  The per-element 32-bit hash of rounds 2 - 4 (seven multiplies and a dozen shifts / xors per value) cost the cross-attention's concat /
+// slice passes 0.22 ms per step; the streaming kernels take whole groups (ge_drop_scale4), the transposing ones single elements.
+__device__ __forceinline__ uint64_t ge_drop_hash4(uint64_t seed, uint64_t group) {
+  uint64_t z = group * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t ge_drop_threshold(float p) { return (uint32_t)(p * 65536.f + 0.5f); }
+__device__ __forceinline__ float ge_drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+  const uint32_t u = (uint32_t)(ge_drop_hash4(seed, idx >> 2) >> (16 * (unsigned)(idx & 3))) & 0xffffu;
+  return u >= thr ? inv_keep : 0.f;
+}
+__device__ __forceinline__ void ge_drop_scale4(uint64_t seed, uint64_t group, uint32_t thr, float inv_keep, float s[4]) {
+  const uint64_t h = ge_drop_hash4(seed, group);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s[e] = (((uint32_t)(h >> (16 * e))) & 0xffffu) >= thr ? inv_keep : 0.f;
+}
 static inline unsigned ge_blocks(long n, int per_block, long cap = 1 << 20) {
   long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;

@@ -12,13 +12,6 @@
 // so the backward pass regenerates the mask instead of storing it.
 #include "common.h"
 
-__device__ __forceinline__ float ge_drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-  uint32_t h = ((uint32_t)idx * 0x9E3779B1u) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u) ^ (uint32_t)seed;
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  h += (uint32_t)(seed >> 32); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-  return ((float)(h >> 8) * (1.f / 16777216.f) >= p) ? inv_keep : 0.f;
-}
-
 #define NECK_TILE 64
 
 // grid (ceil(N/64), ceil(C/64), B), 256 threads.  VEC: N and C multiples of the 16-byte vector, all strides aligned.
@@ -75,7 +68,7 @@ __global__ void __launch_bounds__(256) tokens_from_map_k(const T* __restrict__ m
     if (DROP) {
       const uint64_t base = ((uint64_t)b * (uint64_t)N + (uint64_t)n) * (uint64_t)C + (uint64_t)c;
 #pragma unroll
-      for (int k = 0; k < VN; ++k) v[k] *= ge_drop_scale(seed, base + k, p, inv_keep);
+      for (int k = 0; k < VN; ++k) v[k] *= ge_drop_scale(seed, base + k, ge_drop_threshold(p), inv_keep);
     }
     if (VEC) {
       V8<T>::st(tp + n * C + c, v);
@@ -117,7 +110,7 @@ __global__ void __launch_bounds__(256) map_from_tokens_k(const T* __restrict__ t
     if (DROP) {
       const uint64_t base = ((uint64_t)b * (uint64_t)N + (uint64_t)n) * (uint64_t)C + (uint64_t)c;
 #pragma unroll
-      for (int k = 0; k < VN; ++k) v[k] *= ge_drop_scale(seed, base + k, p, inv_keep);
+      for (int k = 0; k < VN; ++k) v[k] *= ge_drop_scale(seed, base + k, ge_drop_threshold(p), inv_keep);
     }
 #pragma unroll
     for (int k = 0; k < VN; ++k) tile[lane_v + k][r] = v[k];

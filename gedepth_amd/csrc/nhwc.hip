@@ -579,12 +579,6 @@ extern "C" int ge_bilinear_nhwc_bwd(const void* d_out, void* d_in, void* workspa
 }
 
 // ================================================================================================= row concat / glue
-__device__ __forceinline__ float nh_drop_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {      // = ge_drop_scale (neck.hip)
-  uint32_t h = ((uint32_t)idx * 0x9E3779B1u) ^ ((uint32_t)(idx >> 32) * 0x85EBCA77u) ^ (uint32_t)seed;
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  h += (uint32_t)(seed >> 32); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-  return ((float)(h >> 8) * (1.f / 16777216.f) >= p) ? inv_keep : 0.f;
-}
 // out[r, off_a : off_a + Ca] = a[r, :] * drop(r, c) + res[r, :]   (res may be NULL, p may be 0; `a` = B batches of rpb rows, batch
 //                                                                     stride a_bs elements: a token range of a longer sequence)
 // out[r, off_b : off_b + Cb] = b[r, :]                              (b may be NULL: only the first part is written)
@@ -594,6 +588,7 @@ __global__ void __launch_bounds__(256) concat_rows_k(const T* __restrict__ a, lo
                                                      T* __restrict__ out, long R, int Ca, int Cb, int off_a, int off_b, float p, float inv_keep,
                                                      uint64_t seed0, const unsigned long long* __restrict__ salt) {
   const uint64_t seed = ge_salted(seed0, salt);
+  const uint32_t thr = ge_drop_threshold(p);
   constexpr int VN = V8<T>::N;
   const int la = Ca / VN, lb = b ? Cb / VN : 0, lt = la + lb, Co = Ca + Cb;
   const long total = R * lt;
@@ -607,7 +602,12 @@ __global__ void __launch_bounds__(256) concat_rows_k(const T* __restrict__ a, lo
       V8<T>::ld(a + bi * a_bs + (r - bi * rpb) * Ca + c0, v);                 // `a`: rows packed per batch, free batch stride
       if (p > 0.f) {
 #pragma unroll
-        for (int k = 0; k < VN; ++k) v[k] *= nh_drop_scale(seed, (uint64_t)(r * Ca + c0 + k), p, inv_keep);
+        for (int k0 = 0; k0 < VN; k0 += 4) {                                  // Ca and c0 are multiples of VN: whole groups of four indices
+          float sc[4];
+          ge_drop_scale4(seed, (uint64_t)(r * Ca + c0 + k0) >> 2, thr, inv_keep, sc);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k0 + e] *= sc[e];
+        }
       }
       if (res) {
         float q[VN];
@@ -628,6 +628,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) slice_rows_drop_k(const T* __restrict__ d_out, T* __restrict__ d_a, long R, int Ca, int Co, int off_a,
                                                          float p, float inv_keep, uint64_t seed0, const unsigned long long* __restrict__ salt) {
   const uint64_t seed = ge_salted(seed0, salt);
+  const uint32_t thr = ge_drop_threshold(p);
   constexpr int VN = V8<T>::N;
   const int la = Ca / VN;
   const long total = R * la;
@@ -638,7 +639,12 @@ __global__ void __launch_bounds__(256) slice_rows_drop_k(const T* __restrict__ d
     V8<T>::ld(d_out + r * Co + off_a + c0, v);
     if (p > 0.f) {
 #pragma unroll
-      for (int k = 0; k < VN; ++k) v[k] *= nh_drop_scale(seed, (uint64_t)(r * Ca + c0 + k), p, inv_keep);
+      for (int k0 = 0; k0 < VN; k0 += 4) {
+        float sc[4];
+        ge_drop_scale4(seed, (uint64_t)(r * Ca + c0 + k0) >> 2, thr, inv_keep, sc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k0 + e] *= sc[e];
+      }
     }
     V8<T>::st(d_a + r * Ca + c0, v);
   }
