@@ -84,11 +84,16 @@ class DepthBaseDecodeHead(BaseModule, metaclass=ABCMeta):
         return dict(loss_depth=self.loss_decode(depth_pred, depth_gt))
 
     def log_images(self, img, depth_pred, depth_gt, img_meta):
-        """Opt-in (costs a host sync): RGB / normalised pred / normalised gt of the first sample."""
+        """Opt-in (costs a host sync): RGB / normalised pred / normalised gt of the first sample (reference decode_head.py:628-648).
+        ``img_rgb`` is (3, H, W) uint8: ``img[:3] * std + mean`` in float32, clipped to [0, 255], truncated.  The reference de-normalises
+        with ``to_bgr=to_rgb`` and then reverses the channels once more: for ``to_rgb=True`` (every shipped config) that is the tensor's
+        own channel order, for ``to_rgb=False`` the reverse."""
         import numpy as np
         cfg = img_meta['img_norm_cfg']
         show = img.detach()[0:3].permute(1, 2, 0).float().cpu().numpy()
-        show = show * np.asarray(cfg['std'], np.float32) + np.asarray(cfg['mean'], np.float32)
+        show = show * np.asarray(cfg['std'], np.float32).reshape(1, -1) + np.asarray(cfg['mean'], np.float32).reshape(1, -1)
         show = np.clip(show, 0, 255).astype(np.uint8).transpose(2, 0, 1)
-        return {'img_rgb': show, 'img_depth_pred': (depth_pred / depth_pred.max()).detach().cpu(),
+        if not cfg.get('to_rgb', True):
+            show = show[::-1]
+        return {'img_rgb': np.ascontiguousarray(show), 'img_depth_pred': (depth_pred / depth_pred.max()).detach().cpu(),
                 'img_depth_gt': (depth_gt / depth_gt.max()).detach().cpu()}

@@ -1125,7 +1125,7 @@ class _Conv1x1Gemm(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 # two aliases of the parameter's arena slice: the (Cout, Cin) one the GEMM writes, the parameter-shaped one autograd adopts
                 tgt = grad_target(ctx.weight_ref) if (ctx.weight_ref is not None and ctx.w_dtype == _f32) else None
-                out2 = grad_target(ctx.weight_ref).view(Cout, Cin) if tgt is not None else None
+                out2 = tgt.view(Cout, Cin) if tgt is not None else None
                 splits = bricks._split_k(rows)
                 if splits:
                     part = torch.bmm(dy2.view(splits, rows // splits, Cout).transpose(1, 2), x2.view(splits, rows // splits, Cin))

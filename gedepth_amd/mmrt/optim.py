@@ -65,6 +65,7 @@ class GradArena:
         if self.adopt:
             for p in self.params:
                 p.grad = None
+                p._ge_grad_claimed = False
         else:
             self.flat_grad.zero_()
 
@@ -82,6 +83,7 @@ class GradArena:
                 src.append(g.detach())
                 dst.append(v)
             p.grad = v
+            p._ge_grad_claimed = False
         with torch.no_grad():
             if empty:
                 torch._foreach_zero_(empty)
@@ -178,14 +180,27 @@ class GradArena:
             cb(remap)
 
 
+def _claim(p):
+    """At most ONE producer per parameter and step may write into the arena slice.  ``p.grad is None`` alone does not say "first gradient":
+    autograd runs a leaf's AccumulateGrad only after ALL of its uses have produced their gradient, so during the second producer's backward
+    of a weight used twice in one forward (tied weights, one module applied to several inputs) ``p.grad`` is still None — both would get the
+    same storage, the second would overwrite the first and the engine would then sum two aliases of one buffer.  The claim is dropped by
+    ``GradArena.zero_grad`` / ``collect``; a later producer gets None and hands autograd a tensor of its own, which the engine sums with the
+    alias as usual."""
+    if getattr(p, '_ge_grad_claimed', False):
+        return False
+    p._ge_grad_claimed = True
+    return True
+
+
 def grad_target(p, dtype=torch.float32):
     """Where a backward may WRITE the gradient of parameter ``p``: a fresh alias of its arena slice, or None.  Only for the first
-    gradient of a step (``p.grad is None`` after ``zero_grad`` in adopt mode: a second use of the same parameter must accumulate,
-    which autograd does on tensors of its own) and only when the slice has the dtype the producer writes.  Autograd then adopts the alias as
-    ``p.grad`` — same storage as the arena — and ``GradArena.collect`` has nothing to copy (Swin-L: 1.1 GB of gradients per step went
-    through a multi-tensor copy, 0.5 ms at 2 images per GPU)."""
+    producer of a step (``p.grad is None`` after ``zero_grad`` in adopt mode and the slice not yet handed out, see ``_claim``: a second use of
+    the same parameter must accumulate, which autograd does on tensors of its own) and only when the slice has the dtype the producer writes.
+    Autograd then adopts the alias as ``p.grad`` — same storage as the arena — and ``GradArena.collect`` has nothing to copy (Swin-L: 1.1 GB of
+    gradients per step went through a multi-tensor copy, 0.5 ms at 2 images per GPU)."""
     v = getattr(p, '_ge_grad_view', None)
-    if v is None or p.grad is not None or v.dtype != dtype or not v.is_contiguous():
+    if v is None or p.grad is not None or v.dtype != dtype or not v.is_contiguous() or not _claim(p):
         return None
     return v.detach()
 
@@ -197,14 +212,17 @@ def grad_target_ohwi(p):
     if v is None or p.grad is not None or v.dtype != torch.float32 or v.dim() != 4:
         return None
     t = v.detach().permute(0, 2, 3, 1)
-    return t if t.is_contiguous() else None
+    if not t.is_contiguous() or not _claim(p):
+        return None
+    return t
 
 
 def grad_into_arena(p, src, dtype=None):
     """A finished gradient ``src`` (any dtype / layout) -> the parameter's arena slice in one copy (the widening cast that was needed anyway),
-    returned as the alias autograd adopts; falls back to ``src.to(dtype)``."""
+    returned as the alias autograd adopts; falls back to ``src.to(dtype)`` (no slice, a gradient already present, or the slice already
+    handed to another producer this step)."""
     v = getattr(p, '_ge_grad_view', None) if p is not None else None
-    if v is None or p.grad is not None or v.shape != src.shape:
+    if v is None or p.grad is not None or v.shape != src.shape or not _claim(p):
         return src.to(dtype or (p.dtype if p is not None else src.dtype))
     t = v.detach()
     t.copy_(src)

@@ -556,6 +556,20 @@ def parse_losses(losses):
     return loss, {k: float(v) for k, v in log_vars.items()}
 
 
+def log_images(img, depth_pred, depth_gt, mean, std, to_rgb=True):
+    """DepthBaseDecodeHead.log_images, decode_heads/decode_head.py:628-648, for one sample: img (C>=3, H, W) normalised, depth_pred / depth_gt
+    (1, H, W).  ``mmcv.imdenormalize(x, mean, std, to_bgr)`` [mmcv 1.3.13, not vendored] is ``x * std + mean`` in float32 followed by an
+    RGB<->BGR swap when ``to_bgr``; the method passes ``to_bgr = to_rgb`` (:632-635), clips to [0, 255], truncates to uint8 (:636-637),
+    reverses the channel axis once more (:638) and moves it to the front (:639-640); both depth maps are divided by their maximum (:642-643)."""
+    show = img[:3].permute(1, 2, 0).numpy().astype(np.float32)
+    show = show * np.asarray(std, np.float32).reshape(1, -1) + np.asarray(mean, np.float32).reshape(1, -1)
+    if to_rgb:
+        show = show[..., ::-1]
+    show = np.clip(show, 0, 255).astype(np.uint8)[:, :, ::-1]
+    show = show.transpose(0, 2, 1).transpose(1, 0, 2)
+    return dict(img_rgb=np.ascontiguousarray(show), img_depth_pred=depth_pred / depth_pred.max(), img_depth_gt=depth_gt / depth_gt.max())
+
+
 # ============================================================ offline ground-plane (float64)
 def ground_plane(P2, R0_rect, Tr_velo_to_cam, height_img, width_img, cam_height=1.65):
     """tools/preprocess_data_kitti.py:29-53: depth at which each pixel's ray meets the plane

@@ -13,7 +13,7 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-GENERATORS = ['make_golden.py', 'make_golden_mask.py', 'make_golden_ground.py', 'make_golden_ckpt.py', 'make_golden_pipeline.py']
+GENERATORS = ['make_golden.py', 'make_golden_mask.py', 'make_golden_ground.py', 'make_golden_ckpt.py', 'make_golden_pipeline.py', 'make_golden_logimg.py']
 
 
 def main():

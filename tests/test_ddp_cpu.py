@@ -392,6 +392,47 @@ def test_grad_arena_adopts_autograd_gradients():
     assert torch.equal(before, arena.flat_grad)
 
 
+def test_arena_slice_is_handed_out_once_per_parameter_and_step():
+    """One weight used TWICE in a forward (tied weights / a module applied to two inputs) under ``GradArena(adopt=True)``: during the second
+    producer's backward ``p.grad`` is still None (AccumulateGrad runs after all uses), so "p.grad is None" alone would give both producers the
+    same arena slice — the second overwrites the first and the engine sums two aliases of one buffer (measured before the fix: max error 488 on
+    gradients of magnitude 472).  ``optim._claim`` hands the slice out once; the second producer gets a tensor of its own.  All three producer
+    entry points (grad_target via the token Linear, grad_target_ohwi, grad_into_arena), against plain autograd (what the reference does)."""
+    from gedepth_amd.mmrt import bricks
+    from gedepth_amd.mmrt.optim import grad_into_arena, grad_target, grad_target_ohwi
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(16, 24, bias=False)                          # (the bias column sum is a HIP kernel: no CPU path by design)
+    arena = GradArena(lin.parameters(), adopt=True)
+    x1, x2 = torch.randn(5, 40, 16), torch.randn(3, 7, 16)
+    ref_w = lin.weight.detach().clone().requires_grad_(True)
+    (torch.nn.functional.linear(x1, ref_w).square().sum() + 3 * torch.nn.functional.linear(x2, ref_w).sin().sum()).backward()
+    for step in range(2):                                              # twice: zero_grad / collect must drop the claim again
+        arena.zero_grad()
+        y1 = bricks._LinearTokens.apply(x1, lin.weight, None, 0)
+        y2 = bricks._LinearTokens.apply(x2, lin.weight, None, 0)
+        (y1.square().sum() + 3 * y2.sin().sum()).backward()
+        arena.collect()
+        assert torch.allclose(lin.weight.grad, ref_w.grad, rtol=1e-5, atol=1e-5), (step, (lin.weight.grad - ref_w.grad).abs().max().item())
+        assert lin.weight.grad.data_ptr() == arena.views[0].data_ptr() and not lin.weight._ge_grad_claimed
+    # the three entry points share the claim
+    conv = torch.nn.Conv2d(8, 4, 3).to(memory_format=torch.channels_last)
+    a2 = GradArena(conv.parameters(), adopt=True)
+    w = conv.weight
+    for first in (grad_target_ohwi, lambda p: grad_into_arena(p, torch.ones_like(p)), ):
+        a2.zero_grad()
+        t = first(w)
+        assert t is not None and t.data_ptr() == w._ge_grad_view.data_ptr()
+        assert grad_target_ohwi(w) is None and grad_target(w) is None
+        again = grad_into_arena(w, torch.full_like(w, 2.0))
+        assert again.data_ptr() != w._ge_grad_view.data_ptr() and bool((again == 2).all())
+        if first is not grad_target_ohwi:
+            assert bool((w._ge_grad_view == 1).all())                  # the first producer's values were not overwritten
+    a2.collect()
+    assert grad_target_ohwi(w) is None                                 # after collect p.grad is the slice: accumulate through autograd
+    a2.zero_grad()
+    assert grad_target_ohwi(w) is not None
+
+
 def test_bf16_shadow_serves_only_current_values():
     """``lowp`` hands out the optimizer's bf16 shadow view while it reflects the parameter (refresh after the write) and a plain
     cast after any other in-place write (checkpoint load, broadcast through the parameter, init) until the next refresh."""

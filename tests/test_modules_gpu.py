@@ -147,3 +147,52 @@ def test_sine_positional_encoding_fixture(dev, golden):
     pe = SinePositionalEncoding(num_feats=256)
     out = pe(torch.zeros(1, 5, 7, dtype=torch.bool, device=dev))
     close(out, golden('sine_pos')['out'], what='sine positional encoding')
+
+
+def test_log_images_fixture_and_train_step(dev, golden):
+    """`log_images.npz` (the reference's own DepthBaseDecodeHead.log_images, decode_head.py:628-648): the product method on DEVICE tensors gives the
+    same uint8 RGB image and max-normalised depth maps, both channel-order cases, bit for bit.  Then through the model with
+    ``decode_head.log_images=True``: train_step splits the three ``img_*`` entries into ``log_imgs`` (reference depther/base.py:141-148), they
+    describe sample 0 of the batch, and neither the loss nor ``log_vars`` sees them."""
+    import os
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.depth.models import build_depther
+    from gedepth_amd.depth.models.decode_heads.decode_head import DepthBaseDecodeHead
+    from gedepth_amd.mmrt.config import Config
+    from oracle import gedepth_oracle as O
+    g = golden('log_images')
+    img, pred, gt = T(g['img']).to(dev), T(g['depth_pred']).to(dev), T(g['depth_gt']).to(dev)
+    for tag, to_rgb in (('rgb', True), ('bgr', False)):
+        r = DepthBaseDecodeHead.log_images(None, img, pred, gt, dict(img_norm_cfg=dict(mean=g['mean'], std=g['std'], to_rgb=to_rgb)))
+        assert r['img_rgb'].dtype == np.uint8 and np.array_equal(r['img_rgb'], g[f'img_rgb_{tag}'])
+        assert not r['img_depth_pred'].is_cuda and np.array_equal(r['img_depth_pred'].numpy(), g[f'img_depth_pred_{tag}'])
+        assert np.array_equal(r['img_depth_gt'].numpy(), g[f'img_depth_gt_{tag}'])
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'depthformer', 'depthformer_swint_v.py'))
+    cfg.model.pretrained = None
+    cfg.model.backbone.drop_path_rate = 0.0
+    outs = {}
+    for flag in (False, True):
+        cfg.model.decode_head.log_images = flag
+        torch.manual_seed(0)
+        model = build_depther(cfg.model)
+        model.neck.multi_att.dropout.p = 0.0
+        model.neck.self_attn.dropout.p = 0.0
+        load_filled(model, 'logimg')
+        model = model.to(dev).train()
+        batch = synthetic_batch(2, 64, 96, seed=5, valid_fraction=0.3)
+        batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        outs[flag] = (model.train_step(batch, None), batch)
+    (plain, _), (logged, batch) = outs[False], outs[True]
+    assert plain['log_imgs'] == {} and sorted(logged['log_imgs']) == ['img_depth_gt', 'img_depth_pred', 'img_rgb']
+    assert not any('img' in k for k in logged['log_vars'].keys())
+    assert abs(float(plain['loss']) - float(logged['loss'])) <= 1e-6 * abs(float(plain['loss']))
+    norm = batch['img_metas'][0]['img_norm_cfg']
+    want = O.log_images(batch['img'][0].cpu(), torch.ones(1, 1, 1), batch['depth_gt'][0].cpu(), norm['mean'], norm['std'], norm['to_rgb'])
+    li = logged['log_imgs']
+    assert np.array_equal(li['img_rgb'], want['img_rgb']) and li['img_rgb'].shape == (3, 64, 96)
+    assert torch.equal(li['img_depth_gt'], want['img_depth_gt'])
+    p = li['img_depth_pred']
+    assert p.shape[-2:] == (64, 96) or p.shape[-2:] == (32, 48), p.shape        # the head's own resolution (the reference logs it before the loss resize)
+    assert float(p.max()) == 1.0 and float(p.min()) > 0

@@ -152,6 +152,23 @@ def test_dynamic_pe_integer_mask_vs_reference(golden):
             assert torch.equal(prod, T(g[f'{tag}_offset_masked{sfx}']))          # same torch CPU ops: bit-identical
 
 
+def test_log_images_vs_reference_method(golden):
+    """oracle.log_images and the product's DepthBaseDecodeHead.log_images (host arithmetic: runs on CPU tensors) against the arrays the
+    reference's own method returned (tests/golden/make_golden_logimg.py), both channel-order cases: uint8 image bit-exact, depth maps bit-exact."""
+    from gedepth_amd.depth.models.decode_heads.decode_head import DepthBaseDecodeHead
+    g = golden('log_images')
+    img, pred, gt = T(g['img']), T(g['depth_pred']), T(g['depth_gt'])
+    for tag, to_rgb in (('rgb', True), ('bgr', False)):
+        got = O.log_images(img, pred, gt, g['mean'], g['std'], to_rgb)
+        meta = dict(img_norm_cfg=dict(mean=g['mean'], std=g['std'], to_rgb=to_rgb))
+        prod = DepthBaseDecodeHead.log_images(None, img, pred, gt, meta)
+        for r in (got, prod):
+            assert r['img_rgb'].dtype == np.uint8 and np.array_equal(r['img_rgb'], g[f'img_rgb_{tag}'])
+            assert np.array_equal(np.asarray(r['img_depth_pred']), g[f'img_depth_pred_{tag}'])
+            assert np.array_equal(np.asarray(r['img_depth_gt']), g[f'img_depth_gt_{tag}'])
+    assert 0 < (g['img_rgb_rgb'] == 0).mean() < 0.5 and 0 < (g['img_rgb_rgb'] == 255).mean() < 0.5          # both clip edges are exercised
+
+
 def test_known_answers(golden):
     g = golden('known_answers')
     close(O.sigloss(T(g['sig_pred']), T(g['sig_gt'])), g['sig'])
