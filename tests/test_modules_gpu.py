@@ -185,12 +185,12 @@ def test_log_images_fixture_and_train_step(dev, golden):
         batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
         outs[flag] = (model.train_step(batch, None), batch)
     (plain, _), (logged, batch) = outs[False], outs[True]
-    assert plain['log_imgs'] == {} and sorted(logged['log_imgs']) == ['img_depth_gt', 'img_depth_pred', 'img_rgb']
+    assert plain['log_imgs'] == {} and sorted(logged['log_imgs']) == ['decode.img_depth_gt', 'decode.img_depth_pred', 'decode.img_rgb']      # add_prefix(..., 'decode'), encoder_decoder.py
     assert not any('img' in k for k in logged['log_vars'].keys())
     assert abs(float(plain['loss']) - float(logged['loss'])) <= 1e-6 * abs(float(plain['loss']))
     norm = batch['img_metas'][0]['img_norm_cfg']
     want = O.log_images(batch['img'][0].cpu(), torch.ones(1, 1, 1), batch['depth_gt'][0].cpu(), norm['mean'], norm['std'], norm['to_rgb'])
-    li = logged['log_imgs']
+    li = {k.split('.', 1)[1]: v for k, v in logged['log_imgs'].items()}
     assert np.array_equal(li['img_rgb'], want['img_rgb']) and li['img_rgb'].shape == (3, 64, 96)
     assert torch.equal(li['img_depth_gt'], want['img_depth_gt'])
     p = li['img_depth_pred']
