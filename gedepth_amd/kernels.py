@@ -1306,12 +1306,29 @@ _LN_ACC = {}
 
 def _ln_accumulators(device, C):
     """The (copies, 2, C) fp32 accumulators of a LayerNorm backward: one persistent buffer per (device, stream, width), zero on entry — the fold
-    kernel that sums the copies clears them again (ge_layernorm_fold), so no zero-fill launch per layer.  Launches are stream-ordered."""
+    kernel that sums the copies clears them again (ge_layernorm_fold), so no zero-fill launch per layer.  Launches are stream-ordered.
+    A buffer first needed while a stream capture is under way would come from the graph's private pool: it is used for that call only and
+    never cached (eager code must not see graph-pool memory)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream, C)
     buf = _LN_ACC.get(key)
     if buf is None:
-        buf = _LN_ACC[key] = torch.zeros(_LN_COPIES, 2, C, device=device, dtype=_f32)
+        buf = torch.zeros(_LN_COPIES, 2, C, device=device, dtype=_f32)
+        if not torch.cuda.is_current_stream_capturing():
+            _LN_ACC[key] = buf
     return buf
+
+
+def _ln_bwd_and_fold(launch_multi, dwb, C):
+    """accumulate (ge_layernorm_bwd_multi) + fold-and-clear (ge_layernorm_fold) as one unit: if anything fails in between (a launch error, a
+    KeyboardInterrupt, an aborted capture) the accumulators are left dirty and every later LayerNorm backward of this width would silently add
+    them to d_gamma / d_beta — so the cached buffer is dropped (the next call allocates a zeroed one)."""
+    try:
+        launch_multi()
+        return _ln_fold(dwb, C)
+    except BaseException:
+        for k in [k for k, v in _LN_ACC.items() if v is dwb]:
+            del _LN_ACC[k]
+        raise
 
 
 def _ln_fold(dwb, C):
@@ -1348,11 +1365,10 @@ class _LayerNorm(torch.autograd.Function):
             dy = dy.to(_f32)
         dx = torch.empty_like(x)
         dwb = _ln_accumulators(x.device, C)                                                    # see ge_layernorm_bwd_multi
-        PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}]', 2 * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
+        dwb = _ln_bwd_and_fold(lambda: PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}]', 2 * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
             hip.lib().ge_layernorm_bwd_multi(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
                                              hip.ptr(rstd), None, hip.ptr(dx), hip.ptr(dwb), _LN_COPIES, rows, C, hip.stream()),
-            'ge_layernorm_bwd_multi'))
-        dwb = _ln_fold(dwb, C)
+            'ge_layernorm_bwd_multi')), dwb, C)
         return dx, dwb[0], dwb[1], None, None
 
 
@@ -1391,12 +1407,11 @@ class _LayerNormRes(torch.autograd.Function):
             dres = _c(dres.to(x.dtype))
         dx = torch.empty_like(x)
         dwb = _ln_accumulators(x.device, C)
-        PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}{" +res" if dres is not None else ""}]',
+        dwb = _ln_bwd_and_fold(lambda: PROFILER.run(f'layernorm_bwd[{rows}x{C} {_tag(x)}<-{_tag(dy)}{" +res" if dres is not None else ""}]',
                      (2 + (dres is not None)) * x.numel() * _es(x) + dy.numel() * _es(dy), lambda: hip.check(
             hip.lib().ge_layernorm_bwd_multi(hip.ptr(dy), hip.dtype_code(dy), hip.ptr(x), hip.dtype_code(x), hip.ptr(w), hip.ptr(mean),
                                              hip.ptr(rstd), hip.ptr(dres), hip.ptr(dx), hip.ptr(dwb), _LN_COPIES, rows, C, hip.stream()),
-            'ge_layernorm_bwd_multi'))
-        dwb = _ln_fold(dwb, C)
+            'ge_layernorm_bwd_multi')), dwb, C)
         return dx, dwb[0], dwb[1], None, None
 
 

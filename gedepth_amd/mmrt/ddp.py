@@ -240,30 +240,53 @@ class FlatDDP(nn.Module):
 
     def _learn_arrival_order(self):
         """End of a step, order not yet learned.  EVERY rank takes part in one broadcast from rank 0 — whatever happened locally — so
-        the decision is collective: rank 0 sends [valid, arrival sequence]; valid = each of its parameters reported exactly once this
-        step (a parameter without a gradient in that step makes the sequence incomplete: try again next step).  All ranks then
-        permute their arenas identically and re-cut the buckets.  (Round 4 let each rank decide from its own hook history whether to
-        enter the broadcast; ranks that disagreed — e.g. a data-dependent branch — would have hung or paired it with a later
-        all-reduce.)"""
+        the decision is collective: rank 0 sends [valid, arrival sequence].  The sequence is rank 0's hook history with repeats dropped (a
+        step with several backward passes fires a hook more than once: the FIRST arrival counts); valid = every parameter reported (a
+        parameter without a gradient in that step makes the sequence incomplete: try again next step).  On the ``_LEARN_ATTEMPTS``-th
+        incomplete step the silent parameters are appended last, in reverse registration order (they never block a bucket: ``finish``
+        launches what is left), and if no hook ever fired the registration-order layout is kept for good — an order that is never learned
+        would otherwise cost a blocking broadcast + host sync every step and make every hipGraph capture fail.  All ranks then permute their arenas identically and re-cut the buckets.  (Round 4 let each rank decide
+        from its own hook history whether to enter the broadcast; ranks that disagreed would have hung or paired it with a later all-reduce.)"""
         n = len(self.arena.params)
+        self._learn_attempts = getattr(self, '_learn_attempts', 0) + 1
         msg = torch.zeros(n + 1, dtype=torch.int64)
-        if sorted(self._arrival) == list(range(n)):
+        seen, seq = set(), []
+        for idx in self._arrival:
+            if idx not in seen:
+                seen.add(idx)
+                seq.append(idx)
+        last_try = self._learn_attempts >= self._LEARN_ATTEMPTS
+        if len(seq) == n or (seq and last_try):
+            seq += [i for i in range(n - 1, -1, -1) if i not in seen]
             msg[0] = 1
-            msg[1:] = torch.tensor(self._arrival, dtype=torch.int64)
+            msg[1:] = torch.tensor(seq, dtype=torch.int64)
+        elif last_try:
+            msg[0] = 2                                   # nothing ever reported: keep the registration-order layout for good
         dev = self.arena.flat_grad.device
         msg = msg.to(dev)
         dist.broadcast(msg, src=0, group=self.group)
         msg = msg.cpu()
-        if int(msg[0]) != 1:
+        verdict = int(msg[0])
+        if verdict == 2:
+            self._order_learned = True
+            self.arrival_order = None
+            return
+        if verdict != 1:
             return
         seq = [int(v) for v in msg[1:].tolist()]
         self._order_learned = True
         self.arrival_order = seq
-        if self._edge <= 0:                              # re-layout disabled: keep the registration-order buckets, learn nothing else
+        if self._edge <= 0:
+            # re-layout disabled: keep the registration-order buckets, but still launch them in the order in which they become COMPLETE
+            # (the position of a bucket's last-arriving member in the learned sequence), as before the arena learned to move
+            when = {idx: t for t, idx in enumerate(seq)}
+            self.order = sorted(range(len(self.buckets)), key=lambda b: max(when[m] for m in self.buckets[b][2]))
             return
         self.arena.permute(seq)
         self._build_buckets(arrival_layout=True)
         self._register_hooks()
+
+    _LEARN_ATTEMPTS = 3
 
     # ------------------------------------------------------------------ module protocol
     def forward(self, *args, **kwargs):

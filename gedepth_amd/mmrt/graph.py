@@ -25,6 +25,34 @@ import torch
 from .. import hip
 
 
+def quiesce_collectives(timeout=10.0):
+    """Block until the process-group watchdog has retired every collective issued so far — i.e. until the flight recorder lists no entry it
+    has not yet discovered complete (``_dump_nccl_trace(onlyActive=True)``).  Call with the device idle.  Returns the number of polls (>= 1) when
+    the condition was observed; if the recorder is unavailable or disabled (``TORCH_NCCL_TRACE_BUFFER_SIZE=0``: nothing to observe) or the
+    timeout passes, falls back to the timed pause of round 5 (``GE_GRAPH_DDP_SETTLE`` seconds, default 0.5) and returns 0."""
+    import pickle
+    import time
+    polls, t0 = 0, time.monotonic()
+    try:
+        from torch._C._distributed_c10d import _dump_nccl_trace
+        if os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '') == '0':
+            raise RuntimeError('flight recorder disabled')
+        while True:
+            polls += 1
+            trace = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
+            entries = trace.get('entries') if isinstance(trace, dict) else None
+            if entries is None:
+                raise RuntimeError('no flight-recorder entries in the trace')
+            if not entries:
+                return polls
+            if time.monotonic() - t0 > timeout:
+                raise TimeoutError(f'{len(entries)} collectives still not retired')
+            time.sleep(0.002)
+    except Exception:
+        time.sleep(float(os.environ.get('GE_GRAPH_DDP_SETTLE', '0.5')))
+        return 0
+
+
 class GraphedTrainStep:
 
     def __init__(self, model, optimizer, batch, amp_dtype=None, ddp=None, warmup=3, lr_updater=None):
@@ -75,25 +103,52 @@ class GraphedTrainStep:
         lib = hip.lib()
         torch.cuda.synchronize(dev)
         if self.ddp is not None and getattr(self.ddp, 'active', False):
-            # The process group's watchdog thread polls the end events of the collectives of the last EAGER step (every 100 ms) until it has
-            # seen them complete.  Once the RCCL stream has joined the capture, hipEventQuery on such an event fails with
-            # hipErrorCapturedEvent and the watchdog aborts the process (2 - 3 of 5 sessions when the capture followed the last eager step
-            # directly; 0 of 8 with this pause, tools/final_round_run.sh's forced-exchange runs): let it retire them first.
-            import time
-            time.sleep(float(os.environ.get('GE_GRAPH_DDP_SETTLE', '0.5')))
+            # The process group's watchdog thread polls the end events of the collectives of the last EAGER steps until it has seen them
+            # complete.  Once the RCCL stream has joined the capture, hipEventQuery on such an event fails with hipErrorCapturedEvent and
+            # the watchdog aborts the process (2 - 3 of 5 sessions when the capture followed the last eager step directly).  The device is
+            # idle here (synchronize above); what is awaited is the watchdog's BOOK-KEEPING, observed through the process group's flight
+            # recorder: no collective left that it has not yet discovered complete (``quiesce_collectives``; a condition, not a pause).
+            quiesce_collectives()
         g = torch.cuda.CUDAGraph()
+        # the dropout kernels read the registered counter address at LAUNCH time, so it is baked into the captured kernel arguments: it only
+        # has to be registered while this capture runs (a process-wide slot that outlived the capture could be cleared under a newer object,
+        # or point at another device's counter)
         hip.check(lib.ge_rng_salt(self.salt.data_ptr()), 'ge_rng_salt')
         try:
             with torch.cuda.graph(g, stream=self.stream):
                 self.salt.add_(1)
                 self.out = self._step_body()
-        except Exception:
+        finally:
             lib.ge_rng_salt(None)
-            raise
         self.graph = g
         lv = self.out.get('log_vars') if isinstance(self.out, dict) else None
         self._log = (list(lv.keys()), lv.tensor()) if hasattr(lv, 'tensor') and lv.tensor() is not None else None
         return self
+
+    def _capture_collectively(self):
+        """capture(), with the outcome agreed between the ranks: a rank whose capture failed must not run eager collectives against ranks
+        replaying graphs that contain theirs (hang / mismatched pairs).  One MIN all-reduce of a success flag — outside any capture, on every
+        rank, whatever happened locally; if any rank failed, all drop their graphs and train eagerly.  Returns the exception or None."""
+        err = None
+        try:
+            self.capture()
+        except Exception as e:       # an op that cannot be captured (a new code path, a library call that synchronises): train eagerly
+            err = e
+            self.graph = None
+            torch.cuda.synchronize()
+            # hooks that fired during the aborted capture have already counted buckets down and queued captured work handles; gradients
+            # of the aborted step may sit half-written in the arena: start the eager step from a clean slate
+            if self.ddp is not None and hasattr(self.ddp, '_reset'):
+                self.ddp._reset()
+            self.optimizer.zero_grad()
+        if self.ddp is not None and getattr(self.ddp, 'active', False):
+            import torch.distributed as dist
+            ok = torch.tensor([0 if err is not None else 1], device=self.optimizer.arena.flat_param.device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.ddp.group)
+            if int(ok.item()) == 0 and err is None:
+                err = RuntimeError('the capture failed on another rank')
+                self.graph = None
+        return err
 
     def recapture(self):
         """Throw the graph away and capture again (after a change of shapes, or to refresh frozen host-side heuristics)."""
@@ -116,13 +171,11 @@ class GraphedTrainStep:
                 out = self._step_body()
             else:
                 if self.graph is None:
-                    try:
-                        self.capture()           # the capture does not execute: replay it for this step
-                    except Exception as e:       # an op that cannot be captured (a new code path, a library call that synchronises): train eagerly
+                    err = self._capture_collectively()      # the capture does not execute: on success replay it for this step
+                    if err is not None:
                         import warnings
-                        warnings.warn(f'GraphedTrainStep: capture failed ({type(e).__name__}: {e}); continuing with eager steps')
-                        self.disabled, self.graph = True, None
-                        torch.cuda.synchronize()
+                        warnings.warn(f'GraphedTrainStep: capture failed ({type(err).__name__}: {err}); continuing with eager steps')
+                        self.disabled = True
                         out = self._step_body()
                         cur.wait_stream(self.stream)
                         return out
@@ -136,10 +189,8 @@ class GraphedTrainStep:
         return out
 
     def release(self):
-        """Drop the graph (its private memory pool) and unregister the dropout counter.  Call before discarding the object: the
-        library keeps the counter's DEVICE ADDRESS."""
-        if getattr(self, 'salt', None) is not None:
-            hip.lib().ge_rng_salt(None)
+        """Drop the graph (its private memory pool).  The dropout counter stays alive with the object; its address is registered with the
+        library only for the duration of ``capture``."""
         self.graph, self.out = None, None
 
     def __del__(self):

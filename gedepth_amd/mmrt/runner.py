@@ -278,6 +278,11 @@ class IterBasedRunner:
                 self.outputs = self.model.train_step(batch, self.optimizer, **kwargs)
             self.call_hook('after_train_iter')
             self.iter += 1
+        if self.graphed is not None:
+            # what the run did with its graph, then the graph's private memory pool goes back (before evaluation / the next run)
+            self.graph_stats = dict(captured=self.graphed.graph is not None, replays=self.graphed.replays, disabled=self.graphed.disabled)
+            self.graphed.release()
+            self.graphed = None
         self.call_hook('after_run')
 
     # ---------------------------------------------------------------- checkpoints (mmcv layout)

@@ -1,5 +1,7 @@
 """Worker of tests/test_model_gpu.py::test_rccl_gradient_exchange_single_rank (run as a subprocess with GE_DDP_FORCE=1):
-two training steps with FlatDDP active on the nccl (RCCL) backend, world size 1, against the same two steps without DDP."""
+two training steps with FlatDDP active on the nccl (RCCL) backend, world size 1, against the same two steps without DDP; then
+(``graphed``, also the body of test_rccl_world2_eager_vs_graphed on a node with >= 2 GPUs) five steps eager vs five steps through
+GraphedTrainStep with the gradient exchange captured in the hipGraph."""
 import os
 import sys
 
@@ -51,10 +53,89 @@ def run(active):
     return losses, grad
 
 
+def graphed(rank, world):
+    """Eager vs captured step with FlatDDP ACTIVE (RCCL all-reduces inside the hipGraph), 5 steps each from the same seeds.  The capture is
+    preceded by ``quiesce_collectives`` — the process-group watchdog must have retired the eager steps' collectives — which is checked here
+    to be an OBSERVED condition (the flight recorder shows an outstanding collective, then none), not the timed fallback."""
+    from gedepth_amd.depth.datasets.synthetic import synthetic_batch
+    from gedepth_amd.depth.models import build_depther
+    from gedepth_amd.mmrt import graph as G
+    from gedepth_amd.mmrt.config import Config
+    from gedepth_amd.mmrt.ddp import FlatDDP
+    from gedepth_amd.mmrt.optim import build_optimizer
+    os.environ['GE_DDP_FORCE'] = '1'
+    dev = torch.device('cuda', torch.cuda.current_device())
+    # the mechanism on its own: a collective just issued is listed as active until the watchdog has seen it complete
+    t = torch.ones(1 << 20, device=dev)
+    w = dist.all_reduce(t, async_op=True)
+    w.wait()
+    torch.cuda.synchronize()
+    polls = G.quiesce_collectives()
+    assert polls >= 1, 'quiesce_collectives fell back to the timed pause: the flight recorder is not observable here'
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_a.py'))
+    cfg.model.pretrained = None
+    cfg.model.backbone.drop_path_rate = 0.0
+    batch = synthetic_batch(2, 128, 160, seed=21 + rank, device=dev, valid_fraction=0.3)
+    results = {}
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(5)
+        model = build_depther(cfg.model)
+        model.init_weights()
+        model.neck.multi_att.dropout.p = 0.0
+        model.neck.self_attn.dropout.p = 0.0
+        model = model.to(dev).train()
+        optimizer = build_optimizer(model, cfg.optimizer, cfg.optimizer_config.get('grad_clip'))
+        ddp = FlatDDP(model, optimizer.arena, bucket_mb=8)
+        assert ddp.active and ddp.backend == 'nccl'
+        losses = []
+        if mode == 'eager':
+            for it in range(5):
+                optimizer.zero_grad()
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = ddp.train_step(batch, optimizer)
+                out['loss'].backward()
+                ddp.finish()
+                optimizer.step()
+                losses.append(float(out['log_vars']['loss']))
+        else:
+            calls = []
+            orig = G.quiesce_collectives
+            G.quiesce_collectives = lambda *a, **k: calls.append(orig(*a, **k)) or calls[-1]
+            try:
+                gs = G.GraphedTrainStep(model, optimizer, dict(batch), amp_dtype=torch.bfloat16, ddp=ddp, warmup=2)
+                for it in range(5):
+                    out = gs()
+                    losses.append(float(out['log_vars']['loss']))
+            finally:
+                G.quiesce_collectives = orig
+            assert gs.graph is not None and not gs.disabled and gs.replays == 3, (gs.disabled, gs.replays)
+            assert calls and all(c >= 1 for c in calls), calls          # the capture waited on the observed condition
+            gs.release()
+        torch.cuda.synchronize()
+        results[mode] = losses
+    a, b = results['eager'], results['graph']
+    assert all(abs(x - y) <= 2e-2 * abs(x) for x, y in zip(a, b)), (a, b)         # bf16 autocast + fp32 atomics' order, as the 1-GPU graph test
+    if world > 1:                                                                   # the logged loss is the mean over ranks: every rank saw the same
+        t = torch.tensor(b, device=dev, dtype=torch.float64)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi)
+    return a, b
+
+
 def main():
     from gedepth_amd.mmrt.ddp import init_dist
     rank, local, world = init_dist('nccl')
-    assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1
+    assert dist.is_initialized() and dist.get_backend() == 'nccl'
+    if len(sys.argv) > 1 and sys.argv[1] == 'graphed':
+        a, b = graphed(rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print('RCCL_GRAPH_OK', world, a, b)
+        return
+    assert world == 1
     la, ga = run(True)
     lb, gb = run(False)
     # not bit-for-bit: the deformable-attention scatter combines chunks of a value tile with fp32 atomics (run-to-run

@@ -521,6 +521,57 @@ def _worker4(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
+def _worker_silent(rank, world, port, tmp, edge_mb):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GE_DDP_EDGE_MB=edge_mb)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(3)
+    model = Branchy()
+    arena = GradArena(model.parameters(), align=1, adopt=True)
+    ddp = FlatDDP(model, arena, bucket_mb=30 * 4 / 2 ** 20)
+    names = {id(p): n for n, p in model.named_parameters()}
+    g = torch.Generator().manual_seed(1)
+    X, Y = torch.randn(8, 3, generator=g), torch.randn(8, 1, generator=g)
+    learned, orders, grads = [], [], []
+    for step in range(5):
+        arena.zero_grad()
+        use_skip = (edge_mb == '0')                          # re-layout off: every parameter reports; else `skip` NEVER gets a gradient
+        if step == 1 and edge_mb != '0':                     # a step with two backward passes: hooks fire twice (repeats are dropped)
+            (ddp(X[rank * 4:(rank + 1) * 4], False) - Y[rank * 4:(rank + 1) * 4]).pow(2).mean().backward()
+        (ddp(X[rank * 4:(rank + 1) * 4], use_skip) - Y[rank * 4:(rank + 1) * 4]).pow(2).mean().backward()
+        ddp.finish()
+        learned.append(bool(ddp._order_learned))
+        orders.append(list(ddp.order))
+        grads.append({names[id(p)]: v.clone() for p, v in zip(arena.params, arena.views)})
+    torch.save(dict(learned=learned, orders=orders, grads=grads, layout=[names[id(p)] for p in arena.params],
+                    arrival=ddp.arrival_order, buckets=[sorted(m) for _, _, m in ddp.buckets]), os.path.join(tmp, f's{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('edge_mb', ['8', '0'])
+def test_flat_ddp_arrival_order_terminates_and_edge0_keeps_launch_order(tmp_path, edge_mb):
+    """(a) A parameter that NEVER receives a gradient (and a step whose hooks fire twice): the arrival order used to stay unlearned for ever —
+    one blocking broadcast + host sync per step, and every hipGraph capture failing on it.  Now the third incomplete step adopts rank 0's
+    sequence with the silent parameter last, on every rank in the same step; gradients stay the mean over ranks throughout.
+    (b) ``GE_DDP_EDGE_MB=0`` (no arena re-layout): the registration-order buckets are still LAUNCHED in the order in which they complete."""
+    port = free_port()
+    mp.spawn(_worker_silent, args=(2, port, str(tmp_path), edge_mb), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f's{i}.pt', weights_only=False) for i in range(2))
+    assert r0['learned'] == r1['learned'] and r0['orders'] == r1['orders'] and r0['layout'] == r1['layout']
+    for a, b in zip(r0['grads'], r1['grads']):
+        assert all(torch.equal(a[k], b[k]) for k in a)
+    if edge_mb == '0':
+        assert r0['learned'] == [True] * 5                   # complete at the first step
+        assert r0['layout'] == [n for n, _ in Branchy().named_parameters()]          # the arena did not move
+        when = {idx: t for t, idx in enumerate(r0['arrival'])}
+        done = [max(when[m] for m in members) for members in r0['buckets']]
+        assert r0['orders'][-1] == sorted(range(len(done)), key=lambda b: done[b]) and sorted(r0['orders'][-1]) == list(range(len(done)))
+    else:
+        assert r0['learned'] == [False, False, True, True, True]
+        assert r0['layout'][-2:] == ['skip.bias', 'skip.weight'] or set(r0['layout'][-2:]) == {'skip.weight', 'skip.bias'}      # silent parameters last
+        assert all(torch.count_nonzero(g['skip.weight']) == 0 for g in r0['grads'])
+
+
 def test_flat_ddp_gloo_world4_ragged_buckets_and_late_gradients(tmp_path):
     """World size 4 (the N = 4 point of the driver's scaling run): buckets of unequal size with a partial tail bucket, gradients
     that become ready out of bucket order, a parameter without a gradient on SOME RANKS in some steps (its slice is reduced as zeros
