@@ -698,4 +698,4 @@ extern "C" int ge_bias_act_bwd(const void* dy, const void* y, void* dx, float* d
   return GE_ERR_UNSUPPORTED;
 }
 
-extern "C" int ge_abi_version(void) { return 6; }
+extern "C" int ge_abi_version(void) { return 7; }

@@ -1102,3 +1102,460 @@ extern "C" int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, 
   GE_LAUNCH_CHECK();
   return GE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ d_value, value-stationary (round 6)
+// The same contraction as msda_mm_bwd_v_k, dV[r, ch] = sum_q C[q, r] dO[q, ch], with the OUTPUT held still instead of the queries:
+//
+//   work item  = (image, head, level, SUPER-BLOCK of 24 x 16 value positions, a chunk of <= VS_T query tiles that can reach it)
+//   workgroup  = 4 waves; wave w keeps rows [96 w, 96 w + 96) x 64 channels of the super-block in MFMA accumulators for the WHOLE chunk
+//   per tile   = lane (query q = tid >> 3, point p = tid & 7) does the tap arithmetic of ONE sampling point, drops its four coefficients
+//                into the shared [384 rows][32 queries] bf16 image with ds_pk_add_bf16 (corners outside the super-block are skipped: the
+//                neighbouring super-block's item takes them), the tile's 32 gradient rows arrive once by LDS-DMA; after ONE barrier every wave
+//                multiplies its LIVE 32-row blocks (a 12-bit mask OR-ed over the workgroup) against the gradient tile: 4 MFMA per live block
+//   result     = written once per item: plain stores when the super-block has a single chunk (the common case at level 0), fp32 atomics when
+//                its tile list was cut into several chunks (coarse levels: one super-block collects thousands of tiles) — ~1.7 M row flushes
+//                per launch instead of the 23 M of the query-stationary kernel, and no records.
+//
+// Why it can win where the transposed kernel lost: that one pays an atomic flush per (tile, window) — 5.1 G row-instructions/s chip-wide
+// is the limit of the atomic units — this one pays a TILE VISIT per (tile, super-block overlap): 2.2 visits per tile and
+// level at level 0 of the KITTI shape, 1.0 - 2.0 at the coarse levels (tools/ubench/msda_mm/geom_stats.py), each shared by four waves.
+//
+// msda_vs_index_k turns the per-tile tap boxes (left in the workspace by msda_mm_bwd_lw_k) into per-super-block tile lists: one workgroup per
+// (image, head, level), LDS counting sort.  Tiles that would be listed under more than VS_MAXOV super-blocks (incoherent geometry), or all tiles
+// of a segment whose lists overflow their slab, are handed to the atomic kernel msda_mm_bwd_v_k as single-tile runs instead: correct for any
+// geometry, fast for coherent ones.
+#define VS_SW 24
+#define VS_SH 16
+#define VS_ROWS (VS_SW * VS_SH)            // 384 rows = 4 waves x 3 MFMA row blocks
+#define VS_CROW 40                         // bf16 elements per image row (32 queries + 16 B pad: conflict-free 16-byte reads over 16 rows)
+#define VS_IMG (VS_ROWS * VS_CROW)
+#define VS_MAXSB 1024                      // super-blocks of one level at most (LDS counters of the index kernel)
+#define VS_MAXOV 12
+#define VS_OVF 4                           // list slab of a segment: VS_OVF entries per tile
+#ifndef VS_T
+#define VS_T 256                           // tiles per work item at most
+#endif
+#ifndef VS_DIAG
+#define VS_DIAG 0                          // measurement aid: 1 no gradient-row DMA, 2 no scatter, 4 no MFMA, 8 no flush
+#endif
+
+struct VsWs { int* lists; int4* items; int* ctrl; long list_cap; long items_cap; };    // ctrl[x] = items of XCD x, ctrl[8 + x] = its cursor,
+                                                                                         // ctrl[16] = tile visits, ctrl[17] = stray tiles, ctrl[18] = items, ctrl[19] = multi-chunk items
+static int vs_max_sb(const MsdaLevels& lv) {
+  int m = 0;
+  for (int l = 0; l < 4; ++l) m = std::max(m, ((lv.W[l] + VS_SW - 1) / VS_SW) * ((lv.H[l] + VS_SH - 1) / VS_SH));
+  return m;
+}
+static size_t vs_ws_layout(int B, int Nq, int nH, const MsdaLevels& lv, char* base, MvWs* mv, VsWs* vs, size_t* vs_ctrl_off = nullptr) {
+  size_t off = mv_ws_layout(B, Nq, nH, base, mv);
+  const long ntiles = (Nq + 31) / 32, segs = (long)B * nH * 4;
+  const long list_cap = VS_OVF * ntiles;
+  const long items_cap = (segs + MSDA_XCDS - 1) / MSDA_XCDS * (vs_max_sb(lv) + 2 * list_cap / VS_T + 2);
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_lists = take((size_t)segs * list_cap * sizeof(int));
+  const size_t o_items = take((size_t)MSDA_XCDS * items_cap * sizeof(int4));
+  const size_t o_ctrl = take(32 * sizeof(int));
+  if (vs_ctrl_off) *vs_ctrl_off = o_ctrl;
+  if (vs) { vs->lists = (int*)(base + o_lists); vs->items = (int4*)(base + o_items); vs->ctrl = (int*)(base + o_ctrl); vs->list_cap = list_cap; vs->items_cap = items_cap; }
+  return off;
+}
+
+__global__ void __launch_bounds__(256) msda_vs_index_k(MvWs mv, VsWs vs, MsdaLevels lv, int ntiles, int nsegs) {
+  __shared__ int cnt[VS_MAXSB], off[VS_MAXSB + 1], fillp[VS_MAXSB];
+  const int seg = blockIdx.x, tid = threadIdx.x;
+  const int lvl = seg & 3;
+  const int nsx = (lv.W[lvl] + VS_SW - 1) / VS_SW, nsy = (lv.H[lvl] + VS_SH - 1) / VS_SH, nsb = nsx * nsy;
+  const int xcd = (int)(((long)(seg >> 2) * MSDA_XCDS) / (nsegs >> 2));       // image-major, as msda_mm_runs_k
+  for (int i = tid; i < nsb; i += 256) { cnt[i] = 0; fillp[i] = 0; }
+  __syncthreads();
+  const int4* bb = mv.bbox + (long)seg * ntiles;
+  // super-block span of a tile = of the union of its two point-group boxes; false when no tap is inside the map
+  auto span = [&](const int4& v, int& sx0, int& sy0, int& sx1, int& sy1) -> bool {
+    const MvBox u = mv_join(mv_unpack(v.x, v.y), mv_unpack(v.z, v.w));
+    if (!mv_some(u)) return false;
+    sx0 = max(u.x0, 0) / VS_SW; sx1 = min(u.x1 / VS_SW, nsx - 1); sy0 = max(u.y0, 0) / VS_SH; sy1 = min(u.y1 / VS_SH, nsy - 1);
+    return sx1 >= sx0 && sy1 >= sy0;
+  };
+  for (int t = tid; t < ntiles; t += 256) {
+    int sx0, sy0, sx1, sy1;
+    if (!span(bb[t], sx0, sy0, sx1, sy1)) continue;
+    if ((sx1 - sx0 + 1) * (sy1 - sy0 + 1) > VS_MAXOV) continue;
+    for (int y = sy0; y <= sy1; ++y) for (int x = sx0; x <= sx1; ++x) atomicAdd(&cnt[y * nsx + x], 1);
+  }
+  __syncthreads();
+  if (tid == 0) { int s = 0; for (int i = 0; i < nsb; ++i) { off[i] = s; s += cnt[i]; } off[nsb] = s; }
+  __syncthreads();
+  const bool all_stray = off[nsb] > vs.list_cap;
+  int* list = vs.lists + (long)seg * vs.list_cap;
+  int4* runs = mv.runs + (long)xcd * mv.runs_cap * 2;
+  int nstray = 0, nvisit = 0;
+  for (int t = tid; t < ntiles; t += 256) {
+    int sx0, sy0, sx1, sy1;
+    const int4 v = bb[t];
+    if (!span(v, sx0, sy0, sx1, sy1)) continue;
+    const int n = (sx1 - sx0 + 1) * (sy1 - sy0 + 1);
+    if (!all_stray && n <= VS_MAXOV) {
+      nvisit += n;
+      for (int y = sy0; y <= sy1; ++y) for (int x = sx0; x <= sx1; ++x) { const int sb = y * nsx + x; list[off[sb] + atomicAdd(&fillp[sb], 1)] = t; }
+    } else {                                                                  // a run of this one tile for msda_mm_bwd_v_k (record format: msda_mm_runs_k)
+      ++nstray;
+      const MvBox b0 = mv_unpack(v.x, v.y), b1 = mv_unpack(v.z, v.w);
+      const bool s0 = mv_some(b0), s1 = mv_some(b1);
+      const int slot = atomicAdd(mv.ctrl + xcd, 1);
+      runs[2 * slot] = make_int4(seg, t | (1 << 24), s0 ? (b0.y0 << 16) | (b0.x0 & 0xffff) : 0, s0 ? ((b0.y1 - b0.y0 + 1) << 16) | (b0.x1 - b0.x0 + 1) : 0);
+      runs[2 * slot + 1] = make_int4(s1 ? (b1.y0 << 16) | (b1.x0 & 0xffff) : 0, s1 ? ((b1.y1 - b1.y0 + 1) << 16) | (b1.x1 - b1.x0 + 1) : 0, 0, 0);
+    }
+  }
+  int nitems = 0, nmulti = 0;
+  if (!all_stray) {
+    int4* items = vs.items + (long)xcd * vs.items_cap;
+    for (int sb = tid; sb < nsb; sb += 256) {
+      const int n = cnt[sb];
+      if (n == 0) continue;
+      const int chunks = (n + VS_T - 1) / VS_T, per = (n + chunks - 1) / chunks;
+      const int slot = atomicAdd(vs.ctrl + xcd, chunks);
+      for (int c = 0; c < chunks; ++c)      // {segment, super-block, first list entry, entries | single-chunk flag}
+        items[slot + c] = make_int4(seg, sb, (int)((long)seg * vs.list_cap) + off[sb] + c * per, min(per, n - c * per) | (chunks == 1 ? (int)0x80000000 : 0));
+      nitems += chunks; nmulti += chunks > 1 ? chunks : 0;
+    }
+  }
+  if (nvisit) atomicAdd(vs.ctrl + 16, nvisit);
+  if (nstray) atomicAdd(vs.ctrl + 17, nstray);
+  if (nitems) atomicAdd(vs.ctrl + 18, nitems);
+  if (nmulti) atomicAdd(vs.ctrl + 19, nmulti);
+}
+
+struct VsArgs { MmArgs f; const bf16_t* gout; float* d_value; VsWs ws; };
+struct VsRaw { uint32_t o; uint32_t l01, l23; uint32_t own; float rx, ry; };      // offsets (x, y) of the lane's point, four of the 32 logits, the lane's own logit, reference point
+
+typedef short vs_s16x2 __attribute__((ext_vector_type(2)));
+
+// OR over the 8 lanes that share a query / over the wave, on the DPP network
+__device__ __forceinline__ float vs_max8(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));    // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ float vs_sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  return v;
+}
+__device__ __forceinline__ int vs_wave_or(int v) {
+  v |= __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false);
+  v |= __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false);
+  v |= __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false);
+  v |= __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false);
+  v |= __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false);
+  return __builtin_amdgcn_readlane(v, 31) | __builtin_amdgcn_readlane(v, 63);
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) msda_mm_bwd_vs_k(VsArgs va) {
+  __shared__ __attribute__((aligned(16))) bf16_t cimg[2 * VS_IMG];
+  __shared__ __attribute__((aligned(16))) bf16_t stage[2 * 2 * MV_HALF];
+  __shared__ int live[2][4];
+  __shared__ int s_item;
+  const MmArgs& a = va.f;
+  const int nh64 = a.nH * 64;
+  const int xcd = blockIdx.x % MSDA_XCDS;
+  const int nitem = va.ws.ctrl[xcd];
+  const int4* items = va.ws.items + (long)xcd * va.ws.items_cap;
+  int* cursor = va.ws.ctrl + MSDA_XCDS + xcd;
+  {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int i = threadIdx.x * 8; i < 2 * VS_IMG; i += 256 * 8) *(uint4*)(cimg + i) = z;
+  }
+  int c1[4] = {-1, -1, -1, -1}, c2[4] = {-1, -1, -1, -1};                    // image entries this lane wrote in the last / last but one visit
+  const int qlast = a.Nq - 1;
+  for (;;) {
+    __syncthreads();                                                        // the previous item's fragment reads are done
+    if (threadIdx.x == 0) s_item = atomicAdd(cursor, 1);
+    __syncthreads();
+    const int it = __builtin_amdgcn_readfirstlane(s_item);
+    if (it >= nitem) break;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                            // leftovers of the previous item (own column only)
+      if (c1[k] >= 0) cimg[c1[k]] = 0;
+      if (c2[k] >= 0) cimg[c2[k]] = 0;
+      c1[k] = -1; c2[k] = -1;
+    }
+    const int4 rec = items[it];
+    const int seg = __builtin_amdgcn_readfirstlane(rec.x), sb = __builtin_amdgcn_readfirstlane(rec.y);
+    const int first = __builtin_amdgcn_readfirstlane(rec.z), nw = __builtin_amdgcn_readfirstlane(rec.w);
+    const int n = nw & 0x7fffffff;
+    const bool single = nw < 0;
+    const int lvl = seg & 3, bh = seg >> 2, head = bh % a.nH, b = bh / a.nH;
+    const int Wl = a.lv.W[lvl], Hl = a.lv.H[lvl], lstart = a.lv.start[lvl];
+    const int nsx = (Wl + VS_SW - 1) / VS_SW;
+    const int sy = (sb / nsx) * VS_SH, sx = (sb - (sb / nsx) * nsx) * VS_SW;
+    const float fW = (float)Wl, fH = (float)Hl, rW = 1.f / fW, rH = 1.f / fH;
+    const int* list = va.ws.lists + first;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int q = tid >> 3, p = tid & 7, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr_row = (lane >> 5) * 8 + ((lane & 15) >> 2), tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    mm_f32x16 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; }
+    auto tile_at = [&](int i) { return list[min(i, n - 1)]; };
+    auto order_of = [&](int tile) { const int qi = min(tile * 32 + q, qlast); return a.order ? a.order[qi] : qi; };
+    // row-relative byte offsets are 32-bit (vs_supported): uniform 64-bit bases + one zero-extended VGPR per address
+    const char* off_b = (const char*)(a.off + head * 64 + lvl * 16 + p * 2);
+    const char* log4_b = (const char*)(a.logit + head * 32 + p * 4);
+    const char* logo_b = (const char*)(a.logit + head * 32 + lvl * 8 + p);
+    const char* ref_b = (const char*)(a.ref + (long)b * a.ref_sb + (long)lvl * a.ref_sl);
+    const char* go_b = (const char*)(va.gout + head * 64 + p * 8);
+    const uint32_t off_ld2 = (uint32_t)a.off_ld * 2u, log_ld2 = (uint32_t)a.logit_ld * 2u, ref_sq4 = (uint32_t)a.ref_sq * 4u, go_ld2 = (uint32_t)nh64 * 2u;
+    const uint32_t row0 = (uint32_t)b * (uint32_t)a.Nq;
+    auto load_raw = [&](int qq) {                                         // 4 vector loads per lane (the 8 lanes of a query read contiguous bytes)
+      const uint32_t row = row0 + (uint32_t)qq;
+      VsRaw r;
+      r.o = *(const uint32_t*)(off_b + row * off_ld2);
+      const uint2 l4 = *(const uint2*)(log4_b + row * log_ld2);            // logits 4 p .. 4 p + 3 of the 32: any partition serves the max / sum
+      r.l01 = l4.x; r.l23 = l4.y;
+      r.own = *(const bf16_t*)(logo_b + row * log_ld2);                     // the lane's own point at the item's level
+      const float2 rr = *(const float2*)(ref_b + (uint32_t)qq * ref_sq4);
+      r.rx = rr.x; r.ry = rr.y;
+      return r;
+    };
+    // 16 bytes of the lane's OWN query's gradient row (piece p of 8): plain loads into registers, parked in LDS a visit later — the compiler
+    // counts the waits exactly (an LDS-DMA forces vmcnt(0) before every later read of the stage: it cannot tell the buffers apart)
+    auto load_go = [&](int qq) { return (VS_DIAG & 1) ? make_uint4(0, 0, 0, 0) : *(const uint4*)(go_b + (row0 + (uint32_t)qq) * go_ld2); };
+    bf16_t* const st_mine = stage + (p >> 2) * MV_HALF + q * 32 + (p & 3) * 8;
+    // pipeline: a ring of THREE visit slots {raw projections, gradient-row piece, order entry, list entry}; the loop is unrolled by three so
+    // that every slot lives in fixed registers (a register rotation would make the compiler wait for the load it has just issued).  At visit i,
+    // after the barrier, slot i % 3 is refilled for visit i + 3 (raw projections, gradient rows), its order entry for visit i + 6, its list entry
+    // for visit i + 9.  Memory latency under this access pattern is 2 - 4 us (with everything one visit ahead a visit took 2.7 us, all of it waiting)
+    struct Slot { VsRaw raw; uint4 go; int qq, tt; };
+    // order entry of the lane's query in `tile`; bit 31 set = the query does not exist (tail of the last tile)
+    auto order_v = [&](int tile) { const int qi = tile * 32 + q; const int qq = order_of(tile); return qi < a.Nq ? qq : (qq | (int)0x80000000); };
+    auto fill = [&](Slot& sl) {                                            // loads of the slot's next visit from its order entry
+      const int qq = sl.qq & 0x7fffffff;
+      sl.go = load_go(qq);
+      sl.raw = load_raw(qq);
+      sl.raw.own |= (uint32_t)sl.qq & 0x80000000u;                          // validity rides in the unused upper half of the 16-bit logit
+    };
+    Slot S0, S1, S2;
+    S0.qq = order_v(tile_at(0)); S1.qq = order_v(tile_at(1)); S2.qq = order_v(tile_at(2));
+    fill(S0); fill(S1); fill(S2);
+    S0.qq = order_v(tile_at(3)); S1.qq = order_v(tile_at(4)); S2.qq = order_v(tile_at(5));
+    S0.tt = tile_at(6); S1.tt = tile_at(7); S2.tt = tile_at(8);
+    auto visit = [&](Slot& sl, int i) __attribute__((always_inline)) {
+      const int buf = i & 1;
+      bf16_t* img = cimg + buf * VS_IMG;
+      const VsRaw raw0 = sl.raw;
+      const bool qok = (int)raw0.own >= 0;
+      // attention weight of the lane's point: softmax over the 32 logits of (query, head) = 8 lanes x 4 logits
+      float aw;
+      {
+        const float e0 = __uint_as_float(raw0.l01 << 16), e1 = __uint_as_float(raw0.l01 & 0xffff0000u);
+        const float e2 = __uint_as_float(raw0.l23 << 16), e3 = __uint_as_float(raw0.l23 & 0xffff0000u);
+        const float m = vs_max8(fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)));
+        const float sum = vs_sum8((__expf(e0 - m) + __expf(e1 - m)) + (__expf(e2 - m) + __expf(e3 - m)));
+        const float inv = qok ? 1.f / sum : 0.f;
+        aw = __expf(__uint_as_float(raw0.own << 16) - m) * inv;
+      }
+      // the tap arithmetic of mm_taps / msda_mm_bwd_lw_k to the bit (the tile lists come from boxes computed with it)
+      int e[4];                                                              // image row of the four corners, -1 = not in this super-block / masked
+      float w[4];
+      {
+        const float ox = __uint_as_float(raw0.o << 16), oy = __uint_as_float(raw0.o & 0xffff0000u);
+        const float lx = raw0.rx + mm_div(ox, fW, rW), ly = raw0.ry + mm_div(oy, fH, rH);
+        const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+        const bool in = qok && y > -1.f && x > -1.f && y < fH && x < fW;
+        const float xc = fminf(fmaxf(x, -1.f), fW), yc = fminf(fmaxf(y, -1.f), fH);
+        const float xf = floorf(xc), yf = floorf(yc);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float ax = xc - xf, ay = yc - yf;
+        const int xa = min(max(x0, 0), Wl - 1), xb = min(max(x0 + 1, 0), Wl - 1);
+        const int ya = min(max(y0, 0), Hl - 1), yb = min(max(y0 + 1, 0), Hl - 1);
+        const float wgt = in ? aw : 0.f;
+        const float wxa = x0 >= 0 ? (1.f - ax) * wgt : 0.f, wxb = x0 + 1 < Wl ? ax * wgt : 0.f;
+        const float wya = y0 >= 0 ? 1.f - ay : 0.f, wyb = y0 + 1 < Hl ? ay : 0.f;
+        const mm_f16x2 wt = __builtin_bit_cast(mm_f16x2, __builtin_amdgcn_cvt_pkrtz(wya * wxa, wya * wxb));
+        const mm_f16x2 wb = __builtin_bit_cast(mm_f16x2, __builtin_amdgcn_cvt_pkrtz(wyb * wxa, wyb * wxb));
+        w[0] = (float)wt[0]; w[1] = (float)wt[1]; w[2] = (float)wb[0]; w[3] = (float)wb[1];
+        const int cxa = xa - sx, cxb = xb - sx, cya = ya - sy, cyb = yb - sy;
+        const bool ixa = (unsigned)cxa < (unsigned)VS_SW, ixb = (unsigned)cxb < (unsigned)VS_SW, iya = (unsigned)cya < (unsigned)VS_SH, iyb = (unsigned)cyb < (unsigned)VS_SH;
+        e[0] = (ixa && iya && w[0] != 0.f) ? (cya * VS_SW + cxa) : -1;
+        e[1] = (ixb && iya && w[1] != 0.f) ? (cya * VS_SW + cxb) : -1;
+        e[2] = (ixa && iyb && w[2] != 0.f) ? (cyb * VS_SW + cxa) : -1;
+        e[3] = (ixb && iyb && w[3] != 0.f) ? (cyb * VS_SW + cxb) : -1;
+      }
+      int mask = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (c2[k] >= 0) cimg[c2[k]] = 0;                                    // this buffer's entries of two visits ago (read by the MFMAs of visit i - 2)
+        c2[k] = c1[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        c1[k] = -1;
+        if (e[k] >= 0 && !(VS_DIAG & 2)) {
+          mask |= 1 << (e[k] >> 5);
+          const int el = buf * VS_IMG + e[k] * VS_CROW + q;
+          c1[k] = el;
+          const short hv = (short)mm_bf(w[k]);
+          vs_s16x2 pv;
+          pv[0] = (q & 1) ? (short)0 : hv; pv[1] = (q & 1) ? hv : (short)0;
+          __builtin_amdgcn_ds_atomic_fadd_v2bf16(MM_LDS_PTR(vs_s16x2, cimg + (el & ~1)), pv);
+        }
+      }
+      mask = vs_wave_or(mask);
+      if (lane == 0) live[buf][wv] = mask;
+      *(uint4*)(st_mine + buf * 2 * MV_HALF) = sl.go;                        // this visit's gradient rows (loaded three visits ago) -> stage[buf]
+      __syncthreads();
+      fill(sl);                                                             // visit i + 3
+      sl.qq = order_v(sl.tt);                                               // visit i + 6
+      sl.tt = tile_at(i + 9);
+      const int lm = __builtin_amdgcn_readfirstlane(live[buf][0] | live[buf][1] | live[buf][2] | live[buf][3]);
+      const int mine = (lm >> (3 * wv)) & 7;
+      if (mine && !(VS_DIAG & 4)) {
+        const bf16_t* st = stage + buf * 2 * MV_HALF;
+        mm_bf16x8 Bf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const bf16_t* pp = st + half * MV_HALF + (ks * 16 + tr_row) * 32 + tr_col;
+            const mm_bf16x4 u0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, pp));
+            const mm_bf16x4 u1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(MM_LDS_PTR(mm_bf16x4, pp + 4 * 32));
+            Bf[ks][half] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+          if ((mine >> rb) & 1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const mm_bf16x8 A = *(const mm_bf16x8*)(img + ((wv * 3 + rb) * 32 + (lane & 31)) * VS_CROW + ks * 16 + (lane >> 5) * 8);
+              acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf[ks][0], acc[rb][0], 0, 0, 0);
+              acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bf[ks][1], acc[rb][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    // two rounds of the ring per loop iteration: at a loop header the compiler's wait-count bookkeeping treats everything in flight as of
+    // unknown age, so the first use of a prefetched register after it drains the whole queue — once per six visits instead of once per three
+#pragma unroll 1
+    for (int i = 0; i < n; i += 6) {
+      visit(S0, i);
+      if (i + 1 >= n) break;
+      visit(S1, i + 1);
+      if (i + 2 >= n) break;
+      visit(S2, i + 2);
+      if (i + 3 >= n) break;
+      visit(S0, i + 3);
+      if (i + 4 >= n) break;
+      visit(S1, i + 4);
+      if (i + 5 >= n) break;
+      visit(S2, i + 5);
+    }
+    // C/D layout: column = lane & 31 (channel of the half), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-row block
+    if (!(VS_DIAG & 8)) {
+      float* dvb = va.d_value + ((long)b * a.Nv * a.nH + head) * 64 + (lane & 31);
+#pragma unroll
+      for (int rb = 0; rb < 3; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wv * 3 + rb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int y = (m * 2731) >> 16, x = m - y * VS_SW;                  // m / 24 for m < 384
+          const int px = sx + x, py = sy + y;
+          if (px < Wl && py < Hl) {
+            float* dst = dvb + (long)(lstart + mul24(py, Wl) + px) * nh64;
+            const float v0 = acc[rb][0][r], v1 = acc[rb][1][r];
+            if (single) { dst[0] = v0; dst[32] = v1; }
+            else { if (v0 != 0.f) atomicAdd(dst, v0); if (v1 != 0.f) atomicAdd(dst + 32, v1); }
+          }
+        }
+      }
+    }
+  }
+}
+
+static int mv_launch_runs(const MvArgs& va, hipStream_t s) {
+  static int per_cu = 0, n_cu = 0;
+  if (!per_cu) {
+    int dev = 0, v = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return GE_ERR_UNSUPPORTED;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, msda_mm_bwd_v_k, 64, 0) != hipSuccess || v < 1) v = 8;
+    n_cu = pr.multiProcessorCount; per_cu = v;
+  }
+  const long blocks = std::max((long)n_cu * per_cu / MSDA_XCDS * MSDA_XCDS, (long)MSDA_XCDS);
+  msda_mm_bwd_v_k<<<(unsigned)blocks, 64, 0, s>>>(va);
+  GE_LAUNCH_CHECK();
+  return GE_OK;
+}
+
+static int vs_supported(int B, int Nq, int Nv, int nH, int L, int P, int dtype, const MsdaLevels& lv) {
+  if (!msda_mm_supported(B, Nq, Nv, nH, L, P, dtype, lv)) return 0;
+  if (vs_max_sb(lv) > VS_MAXSB) return 0;
+  const long ntiles = (Nq + 31) / 32;
+  if ((long)B * nH * 4 * VS_OVF * ntiles >= (1L << 31) || ntiles >= (1 << 24)) return 0;      // list entries are addressed with 32-bit indices
+  return 1;
+}
+
+extern "C" size_t ge_msda_bwd_vs_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P) {
+  MsdaLevels lv;
+  if (!spatial_hw || B <= 0 || Nq <= 0 || msda_levels(spatial_hw, L, Nv, lv) || !vs_supported(B, Nq, Nv, nH, L, P, GE_BF16, lv)) return 0;
+  return vs_ws_layout(B, Nq, nH, lv, nullptr, nullptr, nullptr);
+}
+
+// Byte offset, inside the workspace, of four ints the index kernel leaves behind: {tile visits, stray tiles, work items, items of multi-chunk super-blocks}
+extern "C" size_t ge_msda_bwd_vs_stats_offset(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P) {
+  MsdaLevels lv;
+  if (!spatial_hw || B <= 0 || Nq <= 0 || msda_levels(spatial_hw, L, Nv, lv) || !vs_supported(B, Nq, Nv, nH, L, P, GE_BF16, lv)) return 0;
+  size_t o = 0;
+  vs_ws_layout(B, Nq, nH, lv, nullptr, nullptr, nullptr, &o);
+  return o + 16 * sizeof(int);
+}
+
+// d_value of ge_msda_fwd_mm on the value-stationary kernel.  `d_value` (B, Nv, nH, 64) f32 must be ZERO on entry (super-blocks nothing samples are
+// not written; multi-chunk super-blocks and stray tiles are accumulated with atomics).  `workspace` (ge_msda_bwd_vs_workspace bytes) must be the one
+// ge_msda_bwd_lw_mm was given for the same inputs: its head holds the per-tile tap boxes that kernel leaves behind.
+extern "C" int ge_msda_bwd_value_vs(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                                    const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out,
+                                    float* d_value, void* workspace, size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P,
+                                    int dtype, void* stream) {
+  if (!spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_value || !workspace || B < 0 || Nq < 0) return GE_ERR_BAD_ARG;
+  MsdaLevels lv;
+  int e = msda_levels(spatial_hw, L, Nv, lv);
+  if (e) return e;
+  if (!vs_supported(B, Nq, Nv, nH, L, P, dtype, lv)) return GE_ERR_UNSUPPORTED;
+  if ((((uintptr_t)off_raw | (uintptr_t)logit_raw | (uintptr_t)d_out) & 15) || off_ld % 8 || logit_ld % 8) return GE_ERR_BAD_ARG;
+  if (B == 0 || Nq == 0) return GE_OK;
+  MvArgs mva;
+  VsArgs va;
+  if (workspace_bytes < vs_ws_layout(B, Nq, nH, lv, (char*)workspace, &mva.ws, &va.ws)) return GE_ERR_BAD_ARG;
+  MmArgs& a = va.f;
+  a.value = nullptr; a.lv = lv;
+  a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
+  a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
+  a.out = nullptr; a.loc_out = nullptr; a.attw_out = nullptr;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = (Nq + 31) / 32;
+  va.gout = (const bf16_t*)d_out; va.d_value = d_value;
+  mva.f = a; mva.gout = va.gout; mva.d_value = d_value;
+  hipStream_t s = ge_stream(stream);
+  hipError_t he = hipMemsetAsync(mva.ws.ctrl, 0, 32 * sizeof(int), s);
+  if (he != hipSuccess) return (int)he;
+  he = hipMemsetAsync(va.ws.ctrl, 0, 32 * sizeof(int), s);
+  if (he != hipSuccess) return (int)he;
+  const int nsegs = B * nH * 4;
+  msda_vs_index_k<<<(unsigned)nsegs, 256, 0, s>>>(mva.ws, va.ws, lv, a.ntiles, nsegs);
+  GE_LAUNCH_CHECK();
+  static int vs_blocks = 0;
+  if (!vs_blocks) {
+    int dev = 0, v = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return GE_ERR_UNSUPPORTED;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, msda_mm_bwd_vs_k, 256, 0) != hipSuccess || v < 1) v = 2;
+    vs_blocks = std::max(pr.multiProcessorCount * v / MSDA_XCDS * MSDA_XCDS, MSDA_XCDS);
+  }
+  msda_mm_bwd_vs_k<<<(unsigned)vs_blocks, 256, 0, s>>>(va);
+  GE_LAUNCH_CHECK();
+  return mv_launch_runs(mva, s);             // stray tiles (none for coherent geometries: the kernel then finds empty run lists)
+}

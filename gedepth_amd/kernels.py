@@ -465,7 +465,8 @@ class _MMValueChoice:
     def __init__(self):
         self.mm_mask, self.calls, self.pending, self.last = 15, 0, None, None
         env = os.environ.get('GE_MSDA_VALUE', '')
-        self.forced = {'mm': 15, 'records': 0}.get(env, int(env) if env.isdigit() else None)
+        self.forced = {'mm': 15, 'records': 0, 'vs': 0}.get(env, int(env) if env.isdigit() else None)
+        self.vs = env == 'vs'                             # the value-stationary kernel (ge_msda_bwd_value_vs): opt-in, see _MSDeformAttnMM.backward
 
     @property
     def use_mm(self):
@@ -551,7 +552,16 @@ class _MSDeformAttnMM(torch.autograd.Function):
         # tap boxes in the shared workspace.  Its cost depends on the geometry (how compact the windows of consecutive query tiles are), the
         # record pipeline's (ge_msda_bwd_value_raw) does not: _mm_value_choice picks per call from the run statistics of earlier calls
         want_dv = ctx.needs_input_grad[0]
+        # round 6: GE_MSDA_VALUE=vs routes d_value through the value-stationary kernel (ge_msda_bwd_value_vs: a workgroup owns a 24 x 16 super-block
+        # of value rows and walks the query tiles that reach it; no records, one write per block).  Built as the review's route (i) and MEASURED
+        # SLOWER at the bench shapes — cross 6.3 vs 4.9 ms, self 4.8 vs 2.0 ms (tools/ubench/msda_mm/vs_time.py): 1.4 M tile visits x 4 waves x ~390
+        # instructions are ~3.5 ms of pure issue time before any latency — so it stays opt-in; it is correct for any geometry (stray tiles fall
+        # back per tile to the atomic kernel) and tested like the other two
+        use_vs = want_dv and os.environ.get('GE_MSDA_VALUE') == 'vs'
+        vs_ws_bytes = int(lib.ge_msda_bwd_vs_workspace(shapes_p, B, Nv, Nq, nH, L, P)) if use_vs else 0
         mm_ws_bytes = int(lib.ge_msda_bwd_mm_workspace(B, Nq, nH, L)) if (want_dv and 'msda_value_mm' not in DISABLED) else 0
+        if vs_ws_bytes:
+            mm_ws_bytes = vs_ws_bytes                 # its head is the ge_msda_bwd_mm_workspace layout (tap boxes, run lists)
         mm_ws = torch.empty(mm_ws_bytes, device=value.device, dtype=torch.uint8) if mm_ws_bytes else None
         PROFILER.run(f'msda_mm_bwd_lw_k[B{B} Nq{Nq} Nv{Nv}]', nb_lw, lambda: hip.check(lib.ge_msda_bwd_lw_mm(
             hip.ptr(value), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
@@ -564,6 +574,12 @@ class _MSDeformAttnMM(torch.autograd.Function):
         d_value = None
         if want_dv:
             d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
+            if vs_ws_bytes:
+                PROFILER.run(f'msda_mm_bwd_vs_k[B{B} Nq{Nq} Nv{Nv}]', raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4, lambda: hip.check(
+                    lib.ge_msda_bwd_value_vs(shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(order),
+                                             hip.ptr(d_out), hip.ptr(d_value), hip.ptr(mm_ws), mm_ws_bytes, B, Nv, Nq, nH, L, P, hip.dtype_code(value), hip.stream()),
+                    'ge_msda_bwd_value_vs'))
+                return d_value.to(value.dtype), d_raw, d_ref, None, None, None, None, None
             rec_ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
             choice, mm_mask = _mm_value_choice((B, Nq, Nv, nH, shapes, str(value.device)), mm_ws is not None, rec_ws_bytes > 0)
             rec_mask = 15 & ~mm_mask

@@ -38,7 +38,8 @@ enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
  * the bias+GELU epilogue, the decoder glue passes and the DDAD front end of the device pipeline; 4: round 4 added the MFMA
  * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw), the token GEMM ge_gemm_nt and ge_conv1x1_nhwc_wgrad;
  * 5: round 5 — ge_msda_bwd_lw_mm takes a workspace, ge_msda_bwd_value_mm / ge_msda_bwd_mm_workspace added; 6: the fused
- * 1x1-convolution + BatchNorm + ReLU + position-add entry points ge_conv1x1_bn_*). */
+ * 1x1-convolution + BatchNorm + ReLU + position-add entry points ge_conv1x1_bn_*; 7: round 6 — the value-stationary d_value kernel
+ * ge_msda_bwd_value_vs / ge_msda_bwd_vs_workspace / ge_msda_bwd_vs_stats_offset). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -212,6 +213,20 @@ size_t ge_msda_bwd_mm_stats_offset(int B, int Nq, int nH, int L);
 int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
                          long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, float* d_value, void* workspace,
                          size_t workspace_bytes, int level_mask, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
+/* d_value of ge_msda_fwd_mm with the OUTPUT held still (round 6, ABI 7; csrc/msda_mm.hip: msda_mm_bwd_vs_k).  Same contraction as
+ * ge_msda_bwd_value_mm, but a workgroup keeps a 24 x 16 super-block of value positions x 64 channels in MFMA accumulators while it walks
+ * the query tiles whose tap boxes reach it (lists built on the device from the boxes ge_msda_bwd_lw_mm leaves in the workspace), and writes the
+ * block once: no records, no flush per query tile.  Replaces mmcv's ms_deformable_col2im grad_value (atomicAdd per tap) as called from
+ * depth/models/necks/hahi.py:316-325.  d_value (B, Nv, nH, 64) f32 must be ZERO on entry.  `workspace`: ge_msda_bwd_vs_workspace(...) bytes
+ * (0 = geometry unsupported), the same buffer that was handed to ge_msda_bwd_lw_mm for these inputs (its head is the
+ * ge_msda_bwd_mm_workspace layout).  Query tiles whose taps are spread over more than 12 super-blocks fall back, per tile, to the
+ * atomic kernel of ge_msda_bwd_value_mm: correct for any geometry.  Four ints {tile visits, stray tiles, work items, items of multi-chunk
+ * super-blocks} of the latest call sit at byte ge_msda_bwd_vs_stats_offset(...) of the workspace. */
+size_t ge_msda_bwd_vs_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P);
+size_t ge_msda_bwd_vs_stats_offset(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P);
+int ge_msda_bwd_value_vs(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld, const float* ref,
+                         long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, float* d_value, void* workspace,
+                         size_t workspace_bytes, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);
 int ge_msda_bwd_value_raw_levels(const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
                                  const float* ref, long ref_sb, long ref_sq, long ref_sl, const void* d_out, float* d_value, void* workspace,
                                  size_t workspace_bytes, int level_mask, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream);

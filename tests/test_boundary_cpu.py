@@ -143,7 +143,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert hip.lib().ge_abi_version() == 6
+    assert hip.lib().ge_abi_version() == 7
     # argument validation happens before any launch, so these are safe without a GPU
     assert hip.lib().ge_bilinear_fwd(None, None, 1, 1, 4, 4, 8, 8, 0, 0, None) == 10001
     assert hip.lib().ge_window_attn_bwd_workspace(2, 11, 35, 3) > 0

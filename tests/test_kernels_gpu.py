@@ -549,6 +549,8 @@ _MM_CASES = {
     'scattered': (((44, 70), (22, 35), (11, 18), (6, 9)), ((37, 41),), 6.0, 'rand', 'randperm'),      # windows of many chunks
     'ragged': (((37, 53), (19, 27), (10, 14), (5, 7)), ((21, 45), (3, 5)), 4.0, 'grid', 'tile'),          # Nq % 32 != 0
     'tiny': (((3, 5), (2, 3), (1, 2), (1, 1)), ((2, 3),), 1.0, 'grid', 'tile'),                          # one partial tile, 1 x 1 level
+    # 36 super-blocks at level 0 and tiles without any locality: the value-stationary kernel hands (nearly) every tile to its atomic fallback
+    'strays': (((88, 140), (44, 70), (22, 35), (11, 18)), ((37, 41),), 6.0, 'rand', 'randperm'),
 }
 
 
@@ -595,7 +597,9 @@ def test_msda_mm_fwd_bwd_vs_oracle(dev, case):
     assert all(e <= 5e-3 for e in l2.values()), l2
     # d_value comes from two kernels selected by a LEVEL MASK (kernels._MMValueChoice; the call above ran all levels on the MFMA kernel):
     # every split must give the same tensor — all levels through the record pipeline, coarse / fine and odd / even splits
-    for mode in ('records', '12', '5', '10'):
+    # ... and the value-stationary kernel (round 6, ge_msda_bwd_value_vs; 'randperm' / random reference points make most tiles STRAY: they take
+    # its per-tile fallback to the atomic kernel, the grid cases the super-block lists)
+    for mode in ('records', '12', '5', '10', 'vs'):
         K._MM_VALUE_CHOICE.clear()
         os.environ['GE_MSDA_VALUE'] = mode
         try:
