@@ -87,6 +87,7 @@ struct MmArgs {
   const int* order;                                                           // query order (Nq) or NULL = identity
   bf16_t* out; float* loc_out; float* attw_out;                               // loc_out / attw_out may be NULL
   int B, Nv, Nq, nH, ntiles;
+  int qpitch;                                                                 // rows per image of the (B * rows) tensors raw / out / d_out / d_raw: Nq, or more when only the first Nq queries of each image are processed (the *_part entry points)
 };
 
 // packed (x, y) 16-bit min / max over the 32 lanes of a half wave on the DPP network (row_shr 1, 2, 4, 8 inside the 16-lane rows, then
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
     const bool qok = qi < a.Nq;
     const int qsafe = qok ? qi : tile * 32;                               // a query that exists (weights are zeroed)
     const int qq = a.order ? a.order[qsafe] : qsafe;
-    const long row = (long)b * a.Nq + qq;
+    const long row = (long)b * a.qpitch + qq;
     const bf16_t* op = a.off + row * a.off_ld + head * 64 + (2 * hv) * 16;
     const float* rp = a.ref + (long)b * a.ref_sb + (long)qq * a.ref_sq + (long)(2 * hv) * a.ref_sl;
     uint4 o0 = *(const uint4*)op, o1 = *(const uint4*)(op + 8);
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
         const int m = i * 8 + row8;
         const int qm = __shfl(qq, m, 64);
         const uint4 v = *(const uint4*)(stage2 + m * 72 + sub8 * 8);
-        if (tile * 32 + m < a.Nq) *(uint4*)(a.out + ((long)b * a.Nq + qm) * nh64 + head * 64 + sub8 * 8) = v;
+        if (tile * 32 + m < a.Nq) *(uint4*)(a.out + ((long)b * a.qpitch + qm) * nh64 + head * 64 + sub8 * 8) = v;
       }
     }
   }
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MM_WAVE
     const bool qok = qi < a.Nq;
     const int qsafe = qok ? qi : tile * 32;
     const int qq = a.order ? a.order[qsafe] : qsafe;
-    const long row = (long)b * a.Nq + qq;
+    const long row = (long)b * a.qpitch + qq;
     const bf16_t* op = a.off + row * a.off_ld + head * 64 + (2 * hv) * 16;
     const float* rp = a.ref + (long)b * a.ref_sb + (long)qq * a.ref_sq + (long)(2 * hv) * a.ref_sl;
     uint4 o0 = *(const uint4*)op, o1 = *(const uint4*)(op + 8);
@@ -653,10 +654,10 @@ extern "C" int ge_msda_mm_supported(const int* spatial_hw, int B, int Nv, int Nq
   return msda_mm_supported(B, Nq, Nv, nH, L, P, dtype, lv);
 }
 
-extern "C" int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
-                              long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, float* loc,
-                              float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
-  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !out || B < 0 || Nq < 0 || (loc == nullptr) != (attw == nullptr)) return GE_ERR_BAD_ARG;
+static int fwd_mm_impl(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                       long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, float* loc,
+                       float* attw, void* out, int B, int Nv, int Nq, int q_pitch, int nH, int L, int P, int dtype, void* stream) {
+  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !out || B < 0 || Nq < 0 || q_pitch < Nq || (loc == nullptr) != (attw == nullptr)) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
   if (e) return e;
@@ -667,17 +668,31 @@ extern "C" int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const vo
   a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
   a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
   a.out = (bf16_t*)out; a.loc_out = loc; a.attw_out = attw;
-  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0; a.qpitch = q_pitch;
   return msda_mm_fwd_launch(a, ge_stream(stream));
+}
+extern "C" int ge_msda_fwd_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                              long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, float* loc,
+                              float* attw, void* out, int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+  return fwd_mm_impl(value, spatial_hw, off_raw, off_ld, logit_raw, logit_ld, ref, ref_sb, ref_sq, ref_sl, order, loc, attw, out, B, Nv, Nq, Nq, nH, L, P, dtype, stream);
+}
+// The first Nq queries of every image only: raw / out are (B, q_pitch, ...) row matrices with q_pitch >= Nq rows per image (the rest is left
+// alone; `order` permutes 0 .. Nq - 1).  Round 6: the self-attention's level-0 queries (75 % of them) take the MFMA kernels, the coarse-level
+// queries — whose 32-query patches span 16 - 64 level-0 cells — stay on the LDS-window kernels (kernels.ms_deform_attn_self_split).
+extern "C" int ge_msda_fwd_mm_part(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                                   long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, void* out, int B,
+                                   int Nv, int Nq, int q_pitch, int nH, int L, int P, int dtype, void* stream) {
+  return fwd_mm_impl(value, spatial_hw, off_raw, off_ld, logit_raw, logit_ld, ref, ref_sb, ref_sq, ref_sl, order, nullptr, nullptr, out, B, Nv, Nq, q_pitch, nH, L, P, dtype,
+                     stream);
 }
 
 // d_off_raw / d_logit_raw (same layout and type as off_raw / logit_raw, fully written) from the gradient of the output; d_value is NOT
 // produced here (ge_msda_bwd_value_* / the binned path).
-extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
-                                 long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order,
-                                 const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, void* workspace,
-                                 int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
-  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_off_raw || !d_logit_raw || B < 0 || Nq < 0) return GE_ERR_BAD_ARG;
+static int bwd_lw_mm_impl(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                          long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order,
+                          const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, void* workspace,
+                          int B, int Nv, int Nq, int q_pitch, int nH, int L, int P, int dtype, void* stream) {
+  if (!value || !spatial_hw || !off_raw || !logit_raw || !ref || !d_out || !d_off_raw || !d_logit_raw || B < 0 || Nq < 0 || q_pitch < Nq) return GE_ERR_BAD_ARG;
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
   if (e) return e;
@@ -691,11 +706,26 @@ extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const
   a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
   a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
   a.out = nullptr; a.loc_out = nullptr; a.attw_out = nullptr;
-  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = 0; a.qpitch = q_pitch;
   ba.gout = (const bf16_t*)d_out;
   ba.d_off = (bf16_t*)d_off_raw; ba.d_off_ld = d_off_ld; ba.d_logit = (bf16_t*)d_logit_raw; ba.d_logit_ld = d_logit_ld;
   ba.bbox = (int4*)workspace;                  // head of the ge_msda_bwd_mm_workspace layout (mv_ws_layout)
   return msda_mm_bwd_lw_launch(ba, ge_stream(stream));
+}
+extern "C" int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                                 long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order,
+                                 const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, void* workspace,
+                                 int B, int Nv, int Nq, int nH, int L, int P, int dtype, void* stream) {
+  return bwd_lw_mm_impl(value, spatial_hw, off_raw, off_ld, logit_raw, logit_ld, ref, ref_sb, ref_sq, ref_sl, order, d_out, d_off_raw, d_off_ld, d_logit_raw,
+                        d_logit_ld, workspace, B, Nv, Nq, Nq, nH, L, P, dtype, stream);
+}
+// ge_msda_bwd_lw_mm for the first Nq queries of every image (see ge_msda_fwd_mm_part): d_out / d_off_raw / d_logit_raw rows beyond them are left alone.
+extern "C" int ge_msda_bwd_lw_mm_part(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw,
+                                      long logit_ld, const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order,
+                                      const void* d_out, void* d_off_raw, long d_off_ld, void* d_logit_raw, long d_logit_ld, int B, int Nv, int Nq,
+                                      int q_pitch, int nH, int L, int P, int dtype, void* stream) {
+  return bwd_lw_mm_impl(value, spatial_hw, off_raw, off_ld, logit_raw, logit_ld, ref, ref_sb, ref_sq, ref_sl, order, d_out, d_off_raw, d_off_ld, d_logit_raw,
+                        d_logit_ld, nullptr, B, Nv, Nq, q_pitch, nH, L, P, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ d_value (round 5)
@@ -1080,7 +1110,7 @@ extern "C" int ge_msda_bwd_value_mm(const int* spatial_hw, const void* off_raw, 
   a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
   a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
   a.out = nullptr; a.loc_out = nullptr; a.attw_out = nullptr;
-  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = (Nq + 31) / 32;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = (Nq + 31) / 32; a.qpitch = Nq;
   va.gout = (const bf16_t*)d_out; va.d_value = d_value;
   hipStream_t s = ge_stream(stream);
   hipError_t he = hipMemsetAsync(va.ws.ctrl, 0, 32 * sizeof(int), s);
@@ -1536,7 +1566,7 @@ extern "C" int ge_msda_bwd_value_vs(const int* spatial_hw, const void* off_raw, 
   a.off = (const bf16_t*)off_raw; a.off_ld = off_ld; a.logit = (const bf16_t*)logit_raw; a.logit_ld = logit_ld;
   a.ref = ref; a.ref_sb = ref_sb; a.ref_sq = ref_sq; a.ref_sl = ref_sl; a.order = order;
   a.out = nullptr; a.loc_out = nullptr; a.attw_out = nullptr;
-  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = (Nq + 31) / 32;
+  a.B = B; a.Nv = Nv; a.Nq = Nq; a.nH = nH; a.ntiles = (Nq + 31) / 32; a.qpitch = Nq;
   va.gout = (const bf16_t*)d_out; va.d_value = d_value;
   mva.f = a; mva.gout = va.gout; mva.d_value = d_value;
   hipStream_t s = ge_stream(stream);

@@ -81,6 +81,9 @@ class MultiScaleDeformableAttention(BaseModule):
         if query_order is not None and 'msda_mm' not in K.DISABLED and K.msda_mm_supported(value, raw, spatial_shapes, nH, L, P):
             # MFMA decomposition on query tiles in `query_order` (csrc/msda_mm.hip); any order gives the same result
             out = K.ms_deform_attn_mm(value, raw, ref, spatial_shapes, query_order, nH, L, P)
+        elif K.msda_self_split_ok(value, raw, spatial_shapes, query_shapes, nH, L, P):
+            # self-attention (queries = the value levels): level-0 queries on the MFMA kernels, coarse-level queries on the window kernels
+            out = K.ms_deform_attn_self_split(value, raw, ref, spatial_shapes, nH, L, P)
         else:
             out = ms_deform_attn_raw(value, raw, ref, spatial_shapes, query_shapes, nH, L, P)
         return self.output_proj(out)

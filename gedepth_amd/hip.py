@@ -40,6 +40,8 @@ SIGNATURES = {
     'ge_msda_bwd_mm_workspace': (_sz, [_i, _i, _i, _i]),
     'ge_msda_bwd_mm_stats_offset': (_sz, [_i, _i, _i, _i]),
     'ge_msda_bwd_value_mm': (_i, [_vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_fwd_mm_part': (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'ge_msda_bwd_lw_mm_part': (_i, [_vp, _vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _l, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'ge_msda_bwd_vs_workspace': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     'ge_msda_bwd_vs_stats_offset': (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     'ge_msda_bwd_value_vs': (_i, [_vp, _vp, _l, _vp, _l, _vp, _l, _l, _l, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),

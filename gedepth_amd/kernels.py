@@ -628,6 +628,132 @@ def ms_deform_attn_mm(value, raw, reference_points, spatial_shapes, order, num_h
     return _MSDeformAttnMM.apply(value, raw, reference_points, order, spatial_shapes, int(num_heads), int(num_levels), int(num_points))
 
 
+class _MSDeformAttnSelfSplit(torch.autograd.Function):
+    """The SELF-attention's sampling (queries = the token maps of the value levels, reference points = their own pixel centres) split by
+    query level (round 6): the level-0 queries — 75 % of them, whose 4 x 8 query patches see compact value windows — run on the MFMA
+    decomposition (ge_msda_fwd_mm_part / ge_msda_bwd_lw_mm_part, rows addressed in place through the row pitch), the coarse-level queries —
+    whose 32-query patches span 16 - 64 level-0 cells, i.e. windows of many chunks — stay on the LDS-window gather kernels (ge_msda_fwd_raw /
+    ge_msda_bwd_raw on contiguous copies of their rows: 8 085 of 32 725).  d_value comes from the record pipeline over ALL queries as before
+    (splitting it costs more than it saves: its count / fill passes are bound by per-launch work).  Measured at 8 x 32 725 queries
+    (tools/ubench/msda_mm/self_split_time.py): forward 1.64 -> 0.51 + 0.51 ms, d_raw 1.73 -> 0.62 + 0.52 ms."""
+
+    @staticmethod
+    def forward(ctx, value, raw, ref, spatial_shapes, n_fine, order_fine, nH, L, P):
+        value, raw = _c(value), _c(raw)
+        B, Nv, _, D = value.shape
+        _, Nq, ld = raw.shape
+        n_off = nH * L * P * 2
+        assert D == 64 and ld == n_off + nH * L * P and raw.dtype == value.dtype == torch.bfloat16 and 0 < n_fine < Nq
+        ref = ref.to(_f32)
+        if ref.stride(3) != 1:
+            ref = ref.contiguous()
+        shapes = tuple(tuple(int(v) for v in hw) for hw in spatial_shapes)
+        arr, _ = _levels(shapes)
+        shapes_p = ctypes.cast(arr, ctypes.c_void_p)
+        lib = hip.lib()
+        out = torch.empty(B, Nq, nH * D, device=value.device, dtype=value.dtype)
+        base = hip.ptr(raw, name='raw')
+        nc = Nq - n_fine
+        PROFILER.run(f'msda_mm_fwd_k[B{B} Nq{n_fine}/{Nq} Nv{Nv}]', value.numel() * 2 + B * n_fine * (ld + nH * D) * 2, lambda: hip.check(lib.ge_msda_fwd_mm_part(
+            hip.ptr(value, name='value'), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+            hip.ptr(order_fine), hip.ptr(out), B, Nv, n_fine, Nq, nH, L, P, hip.GE_BF16, hip.stream()), 'ge_msda_fwd_mm_part'))
+        # coarse-level queries: contiguous copies of their rows for the window kernels (whose row addressing is B * Nq)
+        coarse_shapes = []
+        acc = 0
+        for hw in shapes:
+            acc += hw[0] * hw[1]
+            if acc > n_fine:
+                coarse_shapes.append(hw)
+        assert sum(h * w for h, w in coarse_shapes) == nc, 'n_fine must end on a level boundary'
+        raw_c = raw[:, n_fine:].contiguous()
+        ref_c = ref[:, n_fine:]
+        qarr, nq = _query_grid(coarse_shapes, nc)
+        loc = torch.empty(B, nc, nH, L, P, 2, device=raw.device, dtype=_f32)
+        attw = torch.empty(B, nc, nH, L, P, device=raw.device, dtype=_f32)
+        out_c = torch.empty(B, nc, nH * D, device=value.device, dtype=value.dtype)
+        cbase = hip.ptr(raw_c)
+        PROFILER.run(f'msda_fwd_raw[B{B} Nq{nc} Nv{Nv} bf16]', value.numel() * 2 + raw_c.numel() * 2 + (loc.numel() + attw.numel()) * 4 + out_c.numel() * 2,
+                     lambda: hip.check(lib.ge_msda_fwd_raw(hip.ptr(value), shapes_p, qarr, nq, cbase, ld, cbase + n_off * 2, ld, ref_c.data_ptr(), ref_c.stride(0),
+                                                           ref_c.stride(1), ref_c.stride(2), hip.ptr(loc), hip.ptr(attw), hip.ptr(out_c), B, Nv, nc, nH, L, P,
+                                                           hip.GE_BF16, hip.stream()), 'ge_msda_fwd_raw'))
+        out[:, n_fine:] = out_c
+        ctx.save_for_backward(value, raw, ref, order_fine, loc, attw)
+        ctx.meta = (shapes, tuple(coarse_shapes), n_fine, nH, L, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        value, raw, ref, order_fine, loc, attw = ctx.saved_tensors
+        shapes, coarse_shapes, n_fine, nH, L, P = ctx.meta
+        B, Nv, _, D = value.shape
+        _, Nq, ld = raw.shape
+        nc = Nq - n_fine
+        n_off = nH * L * P * 2
+        d_out = _c(d_out.to(value.dtype))
+        arr, _ = _levels(shapes)
+        shapes_p = ctypes.cast(arr, ctypes.c_void_p)
+        lib = hip.lib()
+        d_raw = torch.empty(B, Nq, ld, device=value.device, dtype=raw.dtype)
+        base, dbase = hip.ptr(raw), hip.ptr(d_raw)
+        PROFILER.run(f'msda_mm_bwd_lw_k[B{B} Nq{n_fine}/{Nq} Nv{Nv}]', value.numel() * 2 + B * n_fine * (2 * ld + nH * D) * 2, lambda: hip.check(lib.ge_msda_bwd_lw_mm_part(
+            hip.ptr(value), shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2), hip.ptr(order_fine),
+            hip.ptr(d_out), dbase, ld, dbase + n_off * 2, ld, B, Nv, n_fine, Nq, nH, L, P, hip.GE_BF16, hip.stream()), 'ge_msda_bwd_lw_mm_part'))
+        d_out_c = d_out[:, n_fine:].contiguous()
+        d_raw_c = torch.empty(B, nc, ld, device=value.device, dtype=raw.dtype)
+        qarr, nq = _query_grid(coarse_shapes, nc)
+        ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, nc, nH, L, P))
+        ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8)
+        cb = hip.ptr(d_raw_c)
+        PROFILER.run(f'msda_bwd_raw[B{B} Nq{nc} Nv{Nv} bf16 lw]', value.numel() * 2 + (loc.numel() + attw.numel()) * 4 + d_raw_c.numel() * 2 + d_out_c.numel() * 2,
+                     lambda: hip.check(lib.ge_msda_bwd_raw(hip.ptr(value), shapes_p, qarr, nq, hip.ptr(loc), hip.ptr(attw), hip.ptr(d_out_c), None, cb, ld, cb + n_off * 2, ld,
+                                                           None, hip.ptr(ws), ws_bytes, B, Nv, nc, nH, L, P, hip.GE_BF16, hip.stream()), 'ge_msda_bwd_raw'))
+        d_raw[:, n_fine:] = d_raw_c
+        d_value = None
+        if ctx.needs_input_grad[0]:
+            d_value = torch.zeros(B, Nv, nH, D, device=value.device, dtype=_f32)
+            ws_bytes = int(lib.ge_msda_bwd_workspace(shapes_p, B, Nv, Nq, nH, L, P))
+            ws = torch.empty(ws_bytes, device=value.device, dtype=torch.uint8)
+            if PROFILER.on:
+                PROFILER.add_stage_bytes((0, B * Nq * n_off * 2, 0, raw.numel() * 2, d_out.numel() * 2 + d_value.numel() * 4))
+            PROFILER.run(f'msda_bwd_value_raw[B{B} Nq{Nq} Nv{Nv}]', B * Nq * n_off * 2 + raw.numel() * 2 + d_out.numel() * 2 + d_value.numel() * 4,
+                         lambda: hip.check(lib.ge_msda_bwd_value_raw(shapes_p, base, ld, base + n_off * 2, ld, ref.data_ptr(), ref.stride(0), ref.stride(1), ref.stride(2),
+                                                                     hip.ptr(d_out), hip.ptr(d_value), hip.ptr(ws), ws_bytes, B, Nv, Nq, nH, L, P, hip.GE_BF16, hip.stream()),
+                                           'ge_msda_bwd_value_raw'))
+            d_value = d_value.to(value.dtype)
+        return d_value, d_raw, None, None, None, None, None, None, None
+
+
+def msda_self_split_ok(value, raw, spatial_shapes, query_shapes, nH, L, P):
+    """The level split of the self-attention's sampling applies: bf16 HIP tensors, queries = the value levels themselves (>= 2 of them), every
+    kernel involved supports the geometry.  ``GE_DISABLE=msda_self_split`` keeps all queries on the window kernels."""
+    if 'msda_self_split' in DISABLED or 'msda_mm' in DISABLED or 'msda_raw' in DISABLED or 'msda_value_raw' in DISABLED or not MSDA_BINNED_BACKWARD:
+        return False
+    shapes = [tuple(int(v) for v in hw) for hw in spatial_shapes]
+    if query_shapes is None or [tuple(int(v) for v in hw) for hw in query_shapes] != shapes or len(shapes) < 2 or L != 4 or P != 8:
+        return False
+    if not (value.is_cuda and value.dtype == torch.bfloat16 and raw.dtype == torch.bfloat16 and value.shape[-1] == 64 and max(max(hw) for hw in shapes) <= 8191):
+        return False
+    B, Nv = value.shape[:2]
+    Nq = raw.shape[1]
+    n_fine = shapes[0][0] * shapes[0][1]
+    if Nq != Nv or not msda_mm_supported(value, raw, shapes, nH, L, P):
+        return False
+    lib = hip.lib()
+    arr, _ = _levels(shapes)
+    sp = ctypes.cast(arr, ctypes.c_void_p)
+    qarr, nq = _query_grid(shapes[1:], Nq - n_fine)
+    return (bool(lib.ge_msda_raw_supported(sp, qarr, nq, B, Nv, Nq - n_fine, nH, L, P)) and int(lib.ge_msda_bwd_workspace(sp, B, Nv, Nq - n_fine, nH, L, P)) > 0
+            and int(lib.ge_msda_bwd_workspace(sp, B, Nv, Nq, nH, L, P)) > 0)
+
+
+def ms_deform_attn_self_split(value, raw, reference_points, spatial_shapes, num_heads=8, num_levels=4, num_points=8):
+    """``ms_deform_attn_raw`` for the self-attention (queries = the value levels) with the level split of ``_MSDeformAttnSelfSplit``."""
+    shapes = [tuple(int(v) for v in hw) for hw in spatial_shapes]
+    n_fine = shapes[0][0] * shapes[0][1]
+    order = msda_tile_order(shapes[:1], value.device)
+    return _MSDeformAttnSelfSplit.apply(value, raw, reference_points, shapes, n_fine, order, int(num_heads), int(num_levels), int(num_points))
+
+
 # ---------------------------------------------------------------------------- channels-last helpers
 _CL = torch.channels_last
 

@@ -39,7 +39,8 @@ enum { GE_OK = 0, GE_ERR_BAD_ARG = 10001, GE_ERR_UNSUPPORTED = 10002 };
  * decomposition of the deformable attention (ge_msda_*_mm, ge_msda_bwd_value_raw), the token GEMM ge_gemm_nt and ge_conv1x1_nhwc_wgrad;
  * 5: round 5 — ge_msda_bwd_lw_mm takes a workspace, ge_msda_bwd_value_mm / ge_msda_bwd_mm_workspace added; 6: the fused
  * 1x1-convolution + BatchNorm + ReLU + position-add entry points ge_conv1x1_bn_*; 7: round 6 — the value-stationary d_value kernel
- * ge_msda_bwd_value_vs / ge_msda_bwd_vs_workspace / ge_msda_bwd_vs_stats_offset). */
+ * ge_msda_bwd_value_vs / ge_msda_bwd_vs_workspace / ge_msda_bwd_vs_stats_offset and the query-range variants ge_msda_fwd_mm_part /
+ * ge_msda_bwd_lw_mm_part). */
 int ge_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -194,6 +195,17 @@ int ge_msda_bwd_lw_mm(const void* value, const int* spatial_hw, const void* off_
                       const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, void* d_off_raw,
                       long d_off_ld, void* d_logit_raw, long d_logit_ld, void* workspace, int B, int Nv, int Nq, int nH, int L, int P,
                       int dtype, void* stream);
+/* ge_msda_fwd_mm / ge_msda_bwd_lw_mm for the FIRST Nq queries of every image (round 6, ABI 7): raw / out / d_out / d_raw are (B, q_pitch, ...) row
+ * matrices with q_pitch >= Nq rows per image, rows beyond Nq are left alone, `order` permutes 0 .. Nq - 1.  Used by the self-attention of
+ * depth/models/necks/hahi.py:279-289: its level-0 queries (75 %) run on these MFMA kernels, the coarse-level queries — whose 32-query patches
+ * span 16 - 64 level-0 cells — on ge_msda_fwd_raw / ge_msda_bwd_raw (measured: forward + d_raw 3.37 -> 2.16 ms at 8 x 32 725 queries). */
+int ge_msda_fwd_mm_part(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                        const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, void* out, int B, int Nv, int Nq, int q_pitch,
+                        int nH, int L, int P, int dtype, void* stream);
+int ge_msda_bwd_lw_mm_part(const void* value, const int* spatial_hw, const void* off_raw, long off_ld, const void* logit_raw, long logit_ld,
+                           const float* ref, long ref_sb, long ref_sq, long ref_sl, const int* order, const void* d_out, void* d_off_raw,
+                           long d_off_ld, void* d_logit_raw, long d_logit_ld, int B, int Nv, int Nq, int q_pitch, int nH, int L, int P, int dtype,
+                           void* stream);
 /* d_value of ge_msda_fwd_mm as the transpose of the forward contraction (round 5, ABI 5; csrc/msda_mm.hip: dV_window = C^T dO on the
  * matrix cores, one fp32 atomic flush per RUN of consecutive query tiles that share a window).  Replaces mmcv's
  * ms_deformable_col2im (atomicAdd into grad_value) as called from depth/models/necks/hahi.py:316-325, and the count / scan / fill /
