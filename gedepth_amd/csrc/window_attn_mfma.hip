@@ -133,6 +133,33 @@ __device__ __forceinline__ void stage_rm(const bf16_t* __restrict__ base, long r
     *(uint4*)(dst + t * RLD + part) = v[it];
   }
 }
+// The two halves of stage_rm, for kernels that fetch the NEXT window's operands into registers while the current one is computed.
+__device__ __forceinline__ void load_rm(const bf16_t* __restrict__ base, long row_stride, int col0, const int* tok,
+                                        const float* __restrict__ padval, int lane, uint4 v[4]) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = lane + it * 64;
+    const int t = piece >> 2, part = (piece & 3) * 8;
+    v[it] = make_uint4(0, 0, 0, 0);
+    if (t < WT) {
+      const int src = tok[t];
+      if (src >= 0) {
+        v[it] = *(const uint4*)(base + (long)src * row_stride + col0 + part);
+      } else if (padval) {
+        const float* pv = padval + col0 + part;
+        v[it] = make_uint4(pack2(pv[0], pv[1]), pack2(pv[2], pv[3]), pack2(pv[4], pv[5]), pack2(pv[6], pv[7]));
+      }
+    }
+  }
+}
+__device__ __forceinline__ void store_rm(bf16_t* dst, int lane, const uint4 v[4]) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = lane + it * 64;
+    const int t = piece >> 2, part = (piece & 3) * 8;
+    *(uint4*)(dst + t * RLD + part) = v[it];
+  }
+}
 // Stage V transposed: vt[d][key], keys >= 49 zero.
 __device__ __forceinline__ void stage_vt(const bf16_t* __restrict__ base, long row_stride, int col0, const int* tok,
                                          const float* __restrict__ padval, bf16_t* vt, int lane) {
@@ -589,7 +616,7 @@ struct WinSmemMfmaBwd2 {
   float bias[NBIAS + 7];
   float dbias[NBIAS + 7];
   float dpad[2][2 * HD];    // per wave
-  WinMeta m;
+  WinMeta m[2];             // token tables of the current and of the next window (double buffer)
 };
 __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                   const float* __restrict__ bias_table, const bf16_t* __restrict__ gout,
@@ -611,25 +638,48 @@ __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* 
 #pragma unroll
     for (int i = 0; i < 16; ++i) dB[kt][i] = 0.f;
 
-  for (int bw = slot; bw < n_bw; bw += wg_per_head) {
+  // Software pipeline over the windows of this persistent workgroup (round 6): the operands of window i + 1 are fetched into registers
+  // (2 operands x 4 pieces per lane = 32 VGPRs; wave 0: q, k; wave 1: v, dO) right after window i's tiles have been parked in LDS, and stay
+  // in flight under all of window i's arithmetic — an item used to start with 2 - 3 us of exposed load latency, 7.6 us per item in total
+  // at four resident workgroups per CU.  The token tables are double-buffered in LDS (one barrier less per window).
+  uint4 pa[4], pb[4];
+  auto fetch = [&](int bw_, const WinMeta& mm) {
+    const int b_ = bw_ / nW;
+    const bf16_t* base_ = qkv + (long)b_ * L * 3 * g.C;
+    if (qt == 0) {
+      load_rm(base_, 3 * g.C, head * HD, mm.tok, qkv_bias, lane, pa);
+      load_rm(base_, 3 * g.C, g.C + head * HD, mm.tok, qkv_bias, lane, pb);
+    } else {
+      load_rm(base_, 3 * g.C, 2 * g.C + head * HD, mm.tok, qkv_bias, lane, pa);
+      load_rm(gout + (long)b_ * L * g.C, g.C, head * HD, mm.tok, nullptr, lane, pb);
+    }
+  };
+  auto meta_of = [&](int bw_, WinMeta& mm) {
+    const int b_ = bw_ / nW, win_ = bw_ - b_ * nW;
+    const int wy_ = win_ / g.nWw, wx_ = win_ - wy_ * g.nWw;
+    fill_meta(g, wy_, wx_, lane, mm);
+  };
+  if (slot < n_bw) {
+    if (qt == 0) meta_of(slot, sm.m[0]);
+    __syncthreads();
+    fetch(slot, sm.m[0]);
+  }
+  int cur = 0;
+  for (int bw = slot; bw < n_bw; bw += wg_per_head, cur ^= 1) {
     const int b = bw / nW, win = bw - b * nW;
     const int wy = win / g.nWw, wx = win - wy * g.nWw;
-    if (qt == 0) fill_meta(g, wy, wx, lane, sm.m);
+    const WinMeta& M = sm.m[cur];
+    if (qt == 0) { store_rm(sm.q, lane, pa); store_rm(sm.k, lane, pb); }
+    else { store_rm(sm.v, lane, pa); store_rm(sm.go, lane, pb); }
+    const int bw_next = bw + wg_per_head;
+    if (bw_next < n_bw && qt == 0) meta_of(bw_next, sm.m[cur ^ 1]);
     __syncthreads();
-    const bf16_t* base = qkv + (long)b * L * 3 * g.C;
-    if (qt == 0) {
-      stage_rm(base, 3 * g.C, head * HD, sm.m.tok, qkv_bias, sm.q, lane);
-      stage_rm(base, 3 * g.C, g.C + head * HD, sm.m.tok, qkv_bias, sm.k, lane);
-    } else {
-      stage_rm(base, 3 * g.C, 2 * g.C + head * HD, sm.m.tok, qkv_bias, sm.v, lane);
-      stage_rm(gout + (long)b * L * g.C, g.C, head * HD, sm.m.tok, nullptr, sm.go, lane);
-    }
-    __syncthreads();
+    if (bw_next < n_bw) fetch(bw_next, sm.m[cur ^ 1]);
 
     f32x16 P[2], dS[2];
     st_tiles_q(sm.k, sm.q, qt, c, hi, P);
     const bool use_mask = g.shift > 0 && (wy == g.nWh - 1 || wx == g.nWw - 1);
-    softmax_q(P, sm.bias, sm.m.meta, qt, c, hi, scale, use_mask);
+    softmax_q(P, sm.bias, M.meta, qt, c, hi, scale, use_mask);
     st_tiles_q(sm.v, sm.go, qt, c, hi, dS);                  // dP^T = V dO^T for this wave's queries
     {
       float delta = 0.f;
@@ -658,7 +708,7 @@ __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* 
         for (int s = 0; s < 2; ++s) dq = mfma_bf16(col8(sm.k, kt * 32 + 16 * s + 4 * hi, c), pack8(dS[kt], 8 * s), dq);
       const int q = qt * 32 + c;
       if (q < WT) {
-        const int dst = sm.m.tok[q];
+        const int dst = M.tok[q];
         if (dst >= 0) store_cols(dq, scale, dqkv + ((long)b * L + dst) * 3 * g.C + head * HD, hi);
       }
     }
@@ -706,7 +756,7 @@ __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* 
       }
       const int key = qt * 32 + c;                           // this wave finishes key tile qt
       if (key < WT) {
-        const int dst = sm.m.tok[key];
+        const int dst = M.tok[key];
         if (dst >= 0) {
           bf16_t* rp = dqkv + ((long)b * L + dst) * 3 * g.C + head * HD;
           store_cols(dkm, scale, rp + g.C, hi);

@@ -66,4 +66,14 @@ for th, tw in ((4, 8), (2, 16), (8, 4), (1, 32), (16, 2)):
     t[f'mm fine {th}x{tw}'] = bench(f'MFMA kernels, level-0 queries, {th} x {tw} tiles', run('mm', 0, n0, KS[:1], K.msda_tile_order(KS[:1], dev, th, tw)))
 for th, tw in ((2, 16), (1, 32)):
     t[f'mm coarse {th}x{tw}'] = bench(f'MFMA kernels, coarse queries, {th} x {tw} tiles', run('mm', n0, nv, KS[1:], K.msda_tile_order(KS[1:], dev, th, tw)))
+n1 = n0 + KS[1][0] * KS[1][1]
+for th, tw in ((4, 8), (2, 16), (2, 8)):
+    if th * tw == 32:
+        o = torch.cat((K.msda_tile_order(KS[:1], dev), K.msda_tile_order(KS[1:2], dev, th, tw) + n0))
+    else:      # 16-query patches of level 1 paired into 32-query tiles
+        o = torch.cat((K.msda_tile_order(KS[:1], dev), K.msda_tile_order(KS[1:2], dev, th, tw) + n0))
+    t[f'mm L0+L1 {th}x{tw}'] = bench(f'MFMA kernels, level-0 + level-1 queries (L1 patches {th} x {tw})', run('mm', 0, n1, KS[:2], o))
+    t[f'mm L1 only {th}x{tw}'] = bench(f'MFMA kernels, level-1 queries only ({th} x {tw})', run('mm', n0, n1, KS[1:2], K.msda_tile_order(KS[1:2], dev, th, tw)))
+t['win L2+L3'] = bench('window kernels, level-2 + level-3 queries', run('win', n1, nv, KS[2:]))
+t['win L1'] = bench('window kernels, level-1 queries', run('win', n0, n1, KS[1:2]))
 print('forward + d_raw totals (us, d_value kernels excluded):', {k: round(v) for k, v in t.items()})
