@@ -1,16 +1,16 @@
 #!/usr/bin/env python
-"""Prints the numbers DESIGN.md §6 / README quote from the tracked profiles of one round:  python tools/round_numbers.py r5"""
+"""Prints the numbers DESIGN.md §6 / README quote from the tracked profiles of one round:  python tools/round_numbers.py r6"""
 import csv
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r5'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r6'
 P = 'profiles/' + tag + '_'
 d = json.load(open(P + 'bench.json'))
 print('bench', d['value'], 'img/s', d['ms_per_step'], 'ms | h2d', d['with_h2d']['value'], '| fp32', d['fp32']['value'], d['fp32']['ms_per_step'])
 r = d['roofline']
 print('roofline', r['kernel'], r['avg_us'], 'us', r['achieved'], 'GB/s frac', r['frac'], 'traffic', r['traffic'])
-for f in ['config3', 'config3_eager', 'config4', 'config5', 'ddp_forced', 'ddp_forced_config3', 'ddp_forced_config3_eager']:
+for f in ['config3', 'config3_eager', 'config4', 'ddp_forced', 'ddp_forced_config3', 'ddp_forced_config3_eager']:
     try:
         x = json.load(open(P + 'bench_' + f + '.json'))
         extra = ''
@@ -21,7 +21,7 @@ for f in ['config3', 'config3_eager', 'config4', 'config5', 'ddp_forced', 'ddp_f
     except FileNotFoundError:
         print(f, 'missing')
 rows = list(csv.DictReader(open(P + 'bench_kernel_stats.csv')))
-n = [int(r_['Calls']) for r_ in rows if r_['Name'].startswith('msda_mm_bwd_lw_k')][0]
+n = [int(r_['Calls']) for r_ in rows if 'adamw_k' in r_['Name']][0]          # one optimizer launch per step (since round 6 msda_mm_bwd_lw_k runs twice per step)
 drain = [r_ for r_ in rows if 'msda_drain' in r_['Name']][0]
 print('steps', n, 'kernel ms/step', round(sum(float(r_['TotalDurationNs']) for r_ in rows) / 1e6 / n, 2), 'launches/step', round(sum(int(r_['Calls']) for r_ in rows) / n))
 print('drain calls', drain['Calls'], 'avg us', float(drain['AverageNs']) / 1e3)
