@@ -25,28 +25,46 @@ import torch
 from .. import hip
 
 
-def quiesce_collectives(timeout=10.0):
-    """Block until the process-group watchdog has retired every collective issued so far — i.e. until the flight recorder lists no entry it
-    has not yet discovered complete (``_dump_nccl_trace(onlyActive=True)``).  Call with the device idle.  Returns the number of polls (>= 1) when
-    the condition was observed; if the recorder is unavailable or disabled (``TORCH_NCCL_TRACE_BUFFER_SIZE=0``: nothing to observe) or the
-    timeout passes, falls back to the timed pause of round 5 (``GE_GRAPH_DDP_SETTLE`` seconds, default 0.5) and returns 0."""
+_CAPTURED_RECORDS = []      # [(first, last)] flight-recorder record ids of collectives recorded DURING a capture: the watchdog never sees those works
+
+
+def _fr_entries():
     import pickle
+    from torch._C._distributed_c10d import _dump_nccl_trace
+    trace = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False))
+    return trace.get('entries') if isinstance(trace, dict) else None
+
+
+def _fr_last_record_id():
+    try:
+        ent = _fr_entries()
+        return max(int(e.get('record_id', -1)) for e in ent) if ent else -1
+    except Exception:
+        return -1
+
+
+def quiesce_collectives(timeout=10.0):
+    """Block until the process-group watchdog has RETIRED every collective issued so far, i.e. has seen it complete and dropped it from the list
+    whose end events it keeps querying.  Observed through the c10d flight recorder: every recorded entry carries ``retired`` (set by the watchdog
+    when it erases the work; ``state`` / ``onlyActive`` are refreshed by the dump itself and say nothing about the watchdog).  The recorder is off
+    unless ``TORCH_FR_BUFFER_SIZE`` (older builds: ``TORCH_NCCL_TRACE_BUFFER_SIZE``) is set before the process group is created —
+    ``mmrt.ddp.init_dist`` sets it.  Call with the device idle.  Returns the number of polls (>= 1) when the condition was observed; if the
+    recorder is off / empty / unavailable, or the timeout passes, falls back to the timed pause of round 5 (``GE_GRAPH_DDP_SETTLE`` seconds,
+    default 0.5) and returns 0."""
     import time
     polls, t0 = 0, time.monotonic()
     try:
-        from torch._C._distributed_c10d import _dump_nccl_trace
-        if os.environ.get('TORCH_NCCL_TRACE_BUFFER_SIZE', '') == '0':
-            raise RuntimeError('flight recorder disabled')
         while True:
             polls += 1
-            trace = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True))
-            entries = trace.get('entries') if isinstance(trace, dict) else None
-            if entries is None:
-                raise RuntimeError('no flight-recorder entries in the trace')
+            entries = _fr_entries()
             if not entries:
+                raise RuntimeError('flight recorder off or empty: nothing to observe')
+            # collectives recorded inside an earlier capture are never handed to the watchdog (they execute at replay): not waited for
+            live = [e for e in entries if not any(a <= int(e.get('record_id', -1)) <= b for a, b in _CAPTURED_RECORDS)]
+            if all(e.get('retired', False) for e in live):
                 return polls
             if time.monotonic() - t0 > timeout:
-                raise TimeoutError(f'{len(entries)} collectives still not retired')
+                raise TimeoutError('collectives still not retired')
             time.sleep(0.002)
     except Exception:
         time.sleep(float(os.environ.get('GE_GRAPH_DDP_SETTLE', '0.5')))
@@ -107,19 +125,26 @@ class GraphedTrainStep:
             # complete.  Once the RCCL stream has joined the capture, hipEventQuery on such an event fails with hipErrorCapturedEvent and
             # the watchdog aborts the process (2 - 3 of 5 sessions when the capture followed the last eager step directly).  The device is
             # idle here (synchronize above); what is awaited is the watchdog's BOOK-KEEPING, observed through the process group's flight
-            # recorder: no collective left that it has not yet discovered complete (``quiesce_collectives``; a condition, not a pause).
+            # recorder: every recorded collective carries ``retired`` (``quiesce_collectives``; a condition, not a pause — the timed pause
+            # remains the fallback when the recorder is off).
             quiesce_collectives()
         g = torch.cuda.CUDAGraph()
         # the dropout kernels read the registered counter address at LAUNCH time, so it is baked into the captured kernel arguments: it only
         # has to be registered while this capture runs (a process-wide slot that outlived the capture could be cleared under a newer object,
         # or point at another device's counter)
         hip.check(lib.ge_rng_salt(self.salt.data_ptr()), 'ge_rng_salt')
+        ddp_on = self.ddp is not None and getattr(self.ddp, 'active', False)
+        rec0 = _fr_last_record_id() if ddp_on else -1
         try:
             with torch.cuda.graph(g, stream=self.stream):
                 self.salt.add_(1)
                 self.out = self._step_body()
         finally:
             lib.ge_rng_salt(None)
+            if ddp_on:
+                rec1 = _fr_last_record_id()
+                if rec1 > rec0:
+                    _CAPTURED_RECORDS.append((rec0 + 1, rec1))
         self.graph = g
         lv = self.out.get('log_vars') if isinstance(self.out, dict) else None
         self._log = (list(lv.keys()), lv.tensor()) if hasattr(lv, 'tensor') and lv.tensor() is not None else None

@@ -71,7 +71,11 @@ def graphed(rank, world):
     w.wait()
     torch.cuda.synchronize()
     polls = G.quiesce_collectives()
-    assert polls >= 1, 'quiesce_collectives fell back to the timed pause: the flight recorder is not observable here'
+    assert polls >= 1, 'quiesce_collectives fell back to the timed pause: the flight recorder is not observable here (init_dist switches it on)'
+    import pickle
+    from torch._C._distributed_c10d import _dump_nccl_trace
+    ent = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False))['entries']
+    assert ent and all(e['retired'] for e in ent), [(e.get('profiling_name'), e.get('retired')) for e in ent][-4:]
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'depthformer', 'depthformer_swint_a.py'))
     cfg.model.pretrained = None
     cfg.model.backbone.drop_path_rate = 0.0
