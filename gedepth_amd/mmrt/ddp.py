@@ -313,8 +313,10 @@ def init_dist(backend='nccl'):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if (world > 1 or os.environ.get('GE_DDP_FORCE') == '1') and not dist.is_initialized():
         # the c10d flight recorder: GraphedTrainStep reads the watchdog's ``retired`` marks from it before a capture (mmrt/graph.py: quiesce_collectives)
-        os.environ.setdefault('TORCH_FR_BUFFER_SIZE', '2000')
-        os.environ.setdefault('TORCH_NCCL_TRACE_BUFFER_SIZE', os.environ['TORCH_FR_BUFFER_SIZE'])
+        # (TORCH_FR_BUFFER_SIZE; its older name TORCH_NCCL_TRACE_BUFFER_SIZE is honoured when the caller has set it; without a recorder the capture
+        # falls back to the timed pause)
+        if 'TORCH_NCCL_TRACE_BUFFER_SIZE' not in os.environ:
+            os.environ.setdefault('TORCH_FR_BUFFER_SIZE', '2000')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
