@@ -255,7 +255,10 @@ int ge_msda_dref(const void* d_off_raw, long off_ld, const int* spatial_hw, floa
  * element index); the seed is a launch argument, so a launch captured in a hipGraph would replay ONE mask for ever.  ge_rng_salt
  * registers a device counter (NULL = none, the default) whose value, read when the kernel EXECUTES, is mixed into every seed: a captured
  * training step increments it inside the graph (one more process-wide knob, like ge_msda_mode; forward and backward of a step must see the
- * same value, i.e. increment it between steps only). */
+ * same value, i.e. increment it between steps only).  The ADDRESS is read on the host when a dropout kernel is LAUNCHED and becomes a kernel
+ * argument: inside a capture it is baked into the graph, so the slot only has to be set while the capture runs (round 6: GraphedTrainStep sets it
+ * before and clears it after the capture; a slot that outlived the capture could be cleared under a newer graph object or point at another device's
+ * counter). */
 int ge_rng_salt(const unsigned long long* device_counter);
 int ge_tokens_from_map(const void* map, long map_bs, const float* pos, void* tok, long tok_bs, int B, int C, long N,
                        float p_drop, unsigned long long seed, int dtype, void* stream);
