@@ -1528,6 +1528,11 @@ static int vs_supported(int B, int Nq, int Nv, int nH, int L, int P, int dtype, 
   if ((long)B * nH * 4 * VS_OVF * ntiles >= (1L << 31) || ntiles >= (1 << 24)) return 0;      // list entries are addressed with 32-bit indices
   return 1;
 }
+// msda_mm_bwd_vs_k forms row addresses as a uniform 64-bit base + a 32-bit byte offset: every row-addressed tensor must stay below 4 GB
+static int vs_offsets_fit(int B, int Nq, int nH, long off_ld, long logit_ld, long ref_sq) {
+  const long rows = (long)B * Nq, lim = 1L << 32;
+  return rows * off_ld * 2 < lim && rows * logit_ld * 2 < lim && rows * nH * 64 * 2 < lim && (long)Nq * (ref_sq < 0 ? -ref_sq : ref_sq) * 4 < lim && ref_sq >= 0;
+}
 
 extern "C" size_t ge_msda_bwd_vs_workspace(const int* spatial_hw, int B, int Nv, int Nq, int nH, int L, int P) {
   MsdaLevels lv;
@@ -1555,7 +1560,7 @@ extern "C" int ge_msda_bwd_value_vs(const int* spatial_hw, const void* off_raw, 
   MsdaLevels lv;
   int e = msda_levels(spatial_hw, L, Nv, lv);
   if (e) return e;
-  if (!vs_supported(B, Nq, Nv, nH, L, P, dtype, lv)) return GE_ERR_UNSUPPORTED;
+  if (!vs_supported(B, Nq, Nv, nH, L, P, dtype, lv) || !vs_offsets_fit(B, Nq, nH, off_ld, logit_ld, ref_sq)) return GE_ERR_UNSUPPORTED;
   if ((((uintptr_t)off_raw | (uintptr_t)logit_raw | (uintptr_t)d_out) & 15) || off_ld % 8 || logit_ld % 8) return GE_ERR_BAD_ARG;
   if (B == 0 || Nq == 0) return GE_OK;
   MvArgs mva;

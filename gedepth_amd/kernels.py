@@ -557,7 +557,9 @@ class _MSDeformAttnMM(torch.autograd.Function):
         # SLOWER at the bench shapes — cross 6.3 vs 4.9 ms, self 4.8 vs 2.0 ms (tools/ubench/msda_mm/vs_time.py): 1.4 M tile visits x 4 waves x ~390
         # instructions are ~3.5 ms of pure issue time before any latency — so it stays opt-in; it is correct for any geometry (stray tiles fall
         # back per tile to the atomic kernel) and tested like the other two
-        use_vs = want_dv and os.environ.get('GE_MSDA_VALUE') == 'vs'
+        # (its kernel addresses rows with 32-bit byte offsets: tensors of 4 GB and more keep the other two kernels)
+        use_vs = (want_dv and os.environ.get('GE_MSDA_VALUE') == 'vs' and B * Nq * ld * 2 < 2 ** 32 and B * Nq * nH * D * 2 < 2 ** 32
+                  and 0 <= ref.stride(1) and Nq * ref.stride(1) * 4 < 2 ** 32)
         vs_ws_bytes = int(lib.ge_msda_bwd_vs_workspace(shapes_p, B, Nv, Nq, nH, L, P)) if use_vs else 0
         mm_ws_bytes = int(lib.ge_msda_bwd_mm_workspace(B, Nq, nH, L)) if (want_dv and 'msda_value_mm' not in DISABLED) else 0
         if vs_ws_bytes:
