@@ -267,8 +267,9 @@ static int win_geom(int B, int H, int W, int nH, int shift, WinGeom& g) {
 }
 static int bwd_wg_per_head(const WinGeom& g) {
   long n_bw = (long)g.B * g.nWh * g.nWw;
-  static const int per_cu = [] { const char* e = getenv("GE_WINATTN_WPC"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 32 ? v : 8; }();
-  long want = (256L * per_cu + g.nH - 1) / g.nH;  // persistent workgroups per CU: 4 are resident (two waves per SIMD, two waves each); 8 measured best (4: +4 %, 6: +3 %)
+  static const int per_cu = [] { const char* e = getenv("GE_WINATTN_WPC"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 32 ? v : 6; }();
+  long want = (256L * per_cu + g.nH - 1) / g.nH;  // persistent workgroups per CU: round 6 — six are resident (three waves per SIMD, two waves each) and exactly one resident
+                                                  // round is best (8: +12 - 20 % on stages 0 / 1); until round 5 four were resident and 8 measured best
   // every persistent workgroup ends with the bias-table scatter (64 LDS atomic instructions per wave) and a workspace row for the second
   // reduction stage: keep at least `min_win` windows per workgroup so that this epilogue is amortised (coarse stages have few windows)
   static const int min_win = [] { const char* e = getenv("GE_WINATTN_MINWIN"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 64 ? v : 3; }();

@@ -618,7 +618,17 @@ struct WinSmemMfmaBwd2 {
   float dpad[2][2 * HD];    // per wave
   WinMeta m[2];             // token tables of the current and of the next window (double buffer)
 };
-__global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+#ifndef WA_BWD_WAVES
+#define WA_BWD_WAVES 3                      // waves per SIMD the register allocation targets: 3 = 168 VGPRs (13 spilled registers), six workgroups per CU.
+                                            // Measured (tools/ubench/winattn_time.py, same session, us per launch at the four Swin stages): 2 waves + pipeline 151 / 117 / 92 / 57,
+                                            // 3 waves without it 151 / 110 / 70 / 57, and with the persistent grid cut to the six resident workgroups per CU
+                                            // (window_attn.hip: bwd_wg_per_head) 130 / 98 / 80 / 60 on a slower box where the 8-per-CU grid gave 153 / 120 / 79 / 61
+#endif
+#ifndef WA_BWD_PREFETCH
+#define WA_BWD_PREFETCH 0                   // 1: the next window's operands are fetched into 32 registers under this window's arithmetic (with 3 waves per
+                                            // SIMD that spills 276 registers; with 2 it gains 7 % on stage 0 — the third wave gains 25 % on stage 2)
+#endif
+__global__ void __launch_bounds__(128, WA_BWD_WAVES) window_attn_bwd_mfma2_k(const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                   const float* __restrict__ bias_table, const bf16_t* __restrict__ gout,
                                                                   bf16_t* __restrict__ dqkv, float* __restrict__ workspace,
                                                                   WinGeom g, float scale, int wg_per_head) {
@@ -662,19 +672,20 @@ __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* 
   if (slot < n_bw) {
     if (qt == 0) meta_of(slot, sm.m[0]);
     __syncthreads();
-    fetch(slot, sm.m[0]);
+    if (WA_BWD_PREFETCH) fetch(slot, sm.m[0]);
   }
   int cur = 0;
   for (int bw = slot; bw < n_bw; bw += wg_per_head, cur ^= 1) {
     const int b = bw / nW, win = bw - b * nW;
     const int wy = win / g.nWw, wx = win - wy * g.nWw;
     const WinMeta& M = sm.m[cur];
+    if (!WA_BWD_PREFETCH) fetch(bw, M);                     // (A/B) no pipeline: load now, as round 5 did
     if (qt == 0) { store_rm(sm.q, lane, pa); store_rm(sm.k, lane, pb); }
     else { store_rm(sm.v, lane, pa); store_rm(sm.go, lane, pb); }
     const int bw_next = bw + wg_per_head;
     if (bw_next < n_bw && qt == 0) meta_of(bw_next, sm.m[cur ^ 1]);
     __syncthreads();
-    if (bw_next < n_bw) fetch(bw_next, sm.m[cur ^ 1]);
+    if (WA_BWD_PREFETCH && bw_next < n_bw) fetch(bw_next, sm.m[cur ^ 1]);
 
     f32x16 P[2], dS[2];
     st_tiles_q(sm.k, sm.q, qt, c, hi, P);
@@ -714,12 +725,13 @@ __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* 
     }
     __syncthreads();                                         // both waves are done with V (dP) and K (dQ): they become the transpose buffers
 
-    // partial dV^T[d][key] = sum_{q in tile} dO^T[d][q] P[q][key];  partial dK^T[d][key] = sum_{q in tile} Q^T[d][q] dS[q][key]
-    f32x16 dv[2], dk[2];
+    // dV^T[d][key] = sum_q dO^T[d][q] P[q][key] and dK^T[d][key] = sum_q Q^T[d][q] dS[q][key] over ALL 64 queries, for the 32 keys of key tile
+    // `qt` (round 6): each wave parks the transposed P (then dS) of ITS query tile in its own dead operand tile (wave 0: v, wave 1: k) and, after
+    // the barrier, contracts BOTH waves' tiles against its own key rows — the full sums, no exchange of fp32 partials through LDS (it cost 32
+    // writes + 32 reads per lane, a barrier and 32 registers)
+    f32x16 dv, dk;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dv[kt][i] = 0.f; dk[kt][i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { dv[i] = 0.f; dk[i] = 0.f; }
     bf16_t* tb = qt == 0 ? sm.v : sm.k;                      // [64 keys][RLD], columns 0..31 = the queries of this wave's tile
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {                   // pass 0: P -> dV ; pass 1: dS -> dK
@@ -730,47 +742,36 @@ __global__ void __launch_bounds__(128, 2) window_attn_bwd_mfma2_k(const bf16_t* 
       __syncthreads();
       const bf16_t* lhs = pass == 0 ? sm.go : sm.q;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 a = col8_lin(lhs, qt * 32 + ks * 16 + hi * 8, c);    // X^T[d = c][8 consecutive queries]
-        const bf16x8 b0 = row8(tb, c, ks * 16 + hi * 8), b1 = row8(tb, 32 + c, ks * 16 + hi * 8);
-        if (pass == 0) { dv[0] = mfma_bf16(a, b0, dv[0]); dv[1] = mfma_bf16(a, b1, dv[1]); }
-        else { dk[0] = mfma_bf16(a, b0, dk[0]); dk[1] = mfma_bf16(a, b1, dk[1]); }
+      for (int x = 0; x < 2; ++x) {                          // query tile x, parked by wave x
+        const bf16_t* tbx = x == 0 ? sm.v : sm.k;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 a = col8_lin(lhs, x * 32 + ks * 16 + hi * 8, c);    // X^T[d = c][8 consecutive queries of tile x]
+          const bf16x8 bb = row8(tbx, qt * 32 + c, ks * 16 + hi * 8);      // keys of this wave's key tile
+          if (pass == 0) dv = mfma_bf16(a, bb, dv);
+          else dk = mfma_bf16(a, bb, dk);
+        }
       }
       __syncthreads();
     }
-    // every operand tile is dead now: the two waves swap their partials for each other's key tile through the same LDS
     {
-      float* xb = (float*)sm.k;                              // k | q | v | go = 20 KB; 8 KB per wave are used
-      const int other = 1 - qt;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        xb[qt * 2048 + r * 64 + lane] = other == 0 ? dk[0][r] : dk[1][r];
-        xb[qt * 2048 + 1024 + r * 64 + lane] = other == 0 ? dv[0][r] : dv[1][r];
-      }
-      __syncthreads();
-      f32x16 dkm, dvm;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        dkm[r] = (qt == 0 ? dk[0][r] : dk[1][r]) + xb[other * 2048 + r * 64 + lane];
-        dvm[r] = (qt == 0 ? dv[0][r] : dv[1][r]) + xb[other * 2048 + 1024 + r * 64 + lane];
-      }
       const int key = qt * 32 + c;                           // this wave finishes key tile qt
       if (key < WT) {
         const int dst = M.tok[key];
         if (dst >= 0) {
           bf16_t* rp = dqkv + ((long)b * L + dst) * 3 * g.C + head * HD;
-          store_cols(dkm, scale, rp + g.C, hi);
-          store_cols(dvm, 1.f, rp + 2 * g.C, hi);
+          store_cols(dk, scale, rp + g.C, hi);
+          store_cols(dv, 1.f, rp + 2 * g.C, hi);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            atomicAdd(&sm.dpad[qt][crow(r, hi)], dkm[r] * scale);         // per-wave accumulators: the sum order stays fixed
-            atomicAdd(&sm.dpad[qt][HD + crow(r, hi)], dvm[r]);
+            atomicAdd(&sm.dpad[qt][crow(r, hi)], dk[r] * scale);           // per-wave accumulators: the sum order stays fixed
+            atomicAdd(&sm.dpad[qt][HD + crow(r, hi)], dv[r]);
           }
         }
       }
     }
-    __syncthreads();
+    // (the loop-top stores of the next window's tiles must not overtake this window's last fragment reads: the second barrier of pass 1 orders them)
   }
   for (int w = 0; w < 2; ++w) {                                // wave after wave: a fixed summation order, bit-reproducible gradients
     if (qt == w) {
