@@ -2,6 +2,10 @@
 resolution) against coarser / finer sort keys, model geometry, forward + d_raw of the MFMA kernels.   python tools/ubench/msda_mm/order_time.py"""
 import sys, torch
 sys.path.insert(0, '.')
+import os as _os
+from gedepth_amd import hip as _hip
+if _os.environ.get('GE_LIB'):                                  # A/B a differently built library
+    _hip.LIB_PATH = _os.path.abspath(_os.environ['GE_LIB'])
 from gedepth_amd import kernels as K
 from gedepth_amd.depth.utils.position_encoding import SinePositionalEncoding
 from gedepth_amd.mmrt.bricks import msda_offset_bias

@@ -3,6 +3,10 @@ all queries / on the level-0 queries only (75 % of them; the coarse-level querie
 with several query-tile shapes.  Prints HIP-event times per kernel.   python tools/ubench/msda_mm/self_split_time.py"""
 import os, sys, torch
 sys.path.insert(0, '.')
+import os as _os
+from gedepth_amd import hip as _hip
+if _os.environ.get('GE_LIB'):                                  # A/B a differently built library
+    _hip.LIB_PATH = _os.path.abspath(_os.environ['GE_LIB'])
 from gedepth_amd import kernels as K
 from gedepth_amd.mmrt.bricks import msda_offset_bias
 dev = 'cuda'
