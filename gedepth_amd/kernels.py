@@ -463,7 +463,10 @@ class _MMValueChoice:
     EVERY = 16                                        # steady state: look at the statistics every 16th call
 
     def __init__(self):
-        self.mm_mask, self.calls, self.pending, self.last = 15, 0, None, None
+        # start on the record pipeline: its cost does not depend on the geometry, and the statistics-only call (~50 us) still runs, so a geometry that favours
+        # the MFMA kernel switches over within a few calls.  (Until round 6 the first calls ran the MFMA kernel: 9 ms each at the bench model's geometry
+        # during warm-up, and a graph captured before the statistics arrived would have kept it.)
+        self.mm_mask, self.calls, self.pending, self.last = 0, 0, None, None
         env = os.environ.get('GE_MSDA_VALUE', '')
         self.forced = {'mm': 15, 'records': 0, 'vs': 0}.get(env, int(env) if env.isdigit() else None)
         self.vs = env == 'vs'                             # the value-stationary kernel (ge_msda_bwd_value_vs): opt-in, see _MSDeformAttnMM.backward

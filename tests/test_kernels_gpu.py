@@ -595,11 +595,11 @@ def test_msda_mm_fwd_bwd_vs_oracle(dev, case):
               d_logits=l2rel(r.grad[..., n_off:].float(), rc.grad[..., n_off:]))
     print(f'\n[msda mm {case}] l2-relative errors vs the fp32 oracle on bf16-rounded inputs: ' + ', '.join(f'{k} {e:.2e}' for k, e in l2.items()))
     assert all(e <= 5e-3 for e in l2.values()), l2
-    # d_value comes from two kernels selected by a LEVEL MASK (kernels._MMValueChoice; the call above ran all levels on the MFMA kernel):
-    # every split must give the same tensor — all levels through the record pipeline, coarse / fine and odd / even splits
+    # d_value comes from two kernels selected by a LEVEL MASK (kernels._MMValueChoice; the call above ran all levels through the record pipeline, the
+    # choice's starting point since round 6): every split must give the same tensor — all levels on the MFMA kernel, coarse / fine and odd / even splits
     # ... and the value-stationary kernel (round 6, ge_msda_bwd_value_vs; 'randperm' / random reference points make most tiles STRAY: they take
     # its per-tile fallback to the atomic kernel, the grid cases the super-block lists)
-    for mode in ('records', '12', '5', '10', 'vs'):
+    for mode in ('mm', '12', '5', '10', 'vs'):
         K._MM_VALUE_CHOICE.clear()
         os.environ['GE_MSDA_VALUE'] = mode
         try:
